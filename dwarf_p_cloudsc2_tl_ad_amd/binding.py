@@ -1,0 +1,154 @@
+"""ctypes binding of the C ABI declared in include/cloudsc2_hip.h (libcloudsc2_hip.so, built in-tree by
+``__graft_entry__.build()`` / ``csrc/Makefile``).
+
+There is deliberately no fallback: if the HIP library is missing, importing this module raises, and every compute
+entry point of the library itself returns CLOUDSC2_ENODEVICE when no GPU is present.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+CLOUDSC2_MAX_NLEV = 200
+CLOUDSC2_EINVAL, CLOUDSC2_ENODEVICE, CLOUDSC2_ETLWRONG = -1, -2, -3
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcloudsc2_hip.so")
+
+
+class Cloudsc2Error(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"cloudsc2 error {code}: {msg}")
+        self.code = code
+
+
+class Params(C.Structure):
+    """struct cloudsc2_params"""
+
+    _DOUBLES = ("rg", "rd", "rcpd", "retv", "rlvtt", "rlstt", "rlmlt", "rtt", "r2es", "r3les", "r3ies", "r4les",
+                "r4ies", "r5les", "r5ies", "r5alvcp", "r5alscp", "ralvdcp", "ralsdcp", "rtwat", "rtice",
+                "rtwat_rtice_r", "rvtmp2", "rclcrit", "rkconv", "rlmin", "rpecons", "rlptrc", "rticecu",
+                "rtwat_rticecu_r")
+    _fields_ = ([(n, C.c_double) for n in _DOUBLES] +
+                [("lphylin", C.c_int), ("levapls2", C.c_int), ("lregcl", C.c_int), ("ldrain1d", C.c_int),
+                 ("nlev", C.c_int), ("reserved", C.c_int), ("ceta", C.c_double * CLOUDSC2_MAX_NLEV)])
+
+    def doubles30(self) -> np.ndarray:
+        """The 30 leading constants in the order oracle/ref_harness.F90 takes them."""
+        return np.array([getattr(self, n) for n in self._DOUBLES], dtype=np.float64)
+
+    def set_ceta(self, ceta) -> "Params":
+        ceta = np.asarray(ceta, dtype=np.float64)
+        if ceta.size > CLOUDSC2_MAX_NLEV:
+            raise ValueError("nlev exceeds CLOUDSC2_MAX_NLEV")
+        self.nlev = int(ceta.size)
+        for k, v in enumerate(ceta):
+            self.ceta[k] = float(v)
+        return self
+
+    def ceta_array(self) -> np.ndarray:
+        return np.array(self.ceta[: self.nlev], dtype=np.float64)
+
+
+class Field(C.Structure):
+    """struct cloudsc2_field"""
+
+    _fields_ = [("ptr", C.c_void_p), ("block_stride", C.c_longlong)]
+
+
+IN_NAMES = ("paph", "pap", "q", "qsat", "t", "l", "i", "lude", "lu", "mfu", "mfd", "gtent", "gtenq", "gtenl",
+            "gteni", "supsat")
+OUT_NAMES = ("tent", "tenq", "tenl", "teni", "clc", "fplsl", "fplsn", "fhpsl", "fhpsn", "covptot")
+
+
+class Inputs(C.Structure):
+    """struct cloudsc2_inputs"""
+
+    _fields_ = [(n, Field) for n in IN_NAMES]
+
+
+class Outputs(C.Structure):
+    """struct cloudsc2_outputs"""
+
+    _fields_ = [(n, Field) for n in OUT_NAMES]
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP library has not been built (run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C dwarf_p_cloudsc2_tl_ad_amd/csrc`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    dp = C.POINTER(C.c_double)
+    pp = C.POINTER(Params)
+    lib.cloudsc2_params_default.argtypes = [pp]
+    lib.cloudsc2_params_default.restype = None
+    lib.cloudsc2_last_error.restype = C.c_char_p
+    lib.cloudsc2_device_available.restype = C.c_int
+    lib.cloudsc2_nl_launch.argtypes = [pp, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(Inputs), C.POINTER(Outputs),
+                                       Field, C.c_double, C.c_void_p]
+    lib.cloudsc2_satur_launch.argtypes = [pp, C.c_int, C.c_int, C.c_int, Field, Field, Field, C.c_void_p]
+    lib.cloudsc2_tl_launch.argtypes = [pp, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(Inputs), C.POINTER(Outputs),
+                                       C.POINTER(Inputs), C.POINTER(Outputs), C.c_void_p]
+    lib.cloudsc2_ad_launch.argtypes = [pp, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(Inputs), C.POINTER(Outputs),
+                                       C.POINTER(Inputs), C.POINTER(Outputs), C.c_void_p, C.c_void_p]
+    lib.cloudsc2_taylor_sums_launch.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(Outputs), C.POINTER(Outputs),
+                                                C.POINTER(Outputs), C.c_double, C.c_void_p, C.c_void_p]
+    lib.cloudsc2_adjoint_norms_launch.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(Inputs), C.POINTER(Field),
+                                                  C.POINTER(Outputs), C.POINTER(Inputs), C.c_void_p, C.c_void_p,
+                                                  C.c_void_p]
+    host18 = [dp] * 18
+    lib.cloudsc2_nl_run.argtypes = [pp, C.c_int, C.c_int, C.c_int, C.c_double] + host18 + [dp]
+    lib.cloudsc2_tl_taylor_run.argtypes = [pp, C.c_int, C.c_int, C.c_int, C.c_double] + host18 + [dp, dp]
+    lib.cloudsc2_ad_symmetry_run.argtypes = [pp, C.c_int, C.c_int, C.c_int, C.c_double] + host18 + [dp, dp]
+    lib.cloudsc2_release_workspace.restype = None
+    lib.cloudsc2_taylor_verdict.argtypes = [dp, C.POINTER(C.c_int)]
+    lib.cloudsc2_adjoint_verdict.argtypes = [C.c_double]
+    for name in ("cloudsc2_nl_launch", "cloudsc2_satur_launch", "cloudsc2_tl_launch", "cloudsc2_ad_launch",
+                 "cloudsc2_taylor_sums_launch", "cloudsc2_adjoint_norms_launch", "cloudsc2_nl_run",
+                 "cloudsc2_tl_taylor_run", "cloudsc2_ad_symmetry_run", "cloudsc2_taylor_verdict",
+                 "cloudsc2_adjoint_verdict"):
+        getattr(lib, name).restype = C.c_int
+    return lib
+
+
+lib = _load()
+
+# every symbol include/cloudsc2_hip.h declares
+EXPORTED = ("cloudsc2_params_default", "cloudsc2_last_error", "cloudsc2_device_available", "cloudsc2_nl_launch",
+            "cloudsc2_satur_launch", "cloudsc2_tl_launch", "cloudsc2_ad_launch", "cloudsc2_taylor_sums_launch",
+            "cloudsc2_adjoint_norms_launch", "cloudsc2_nl_run", "cloudsc2_tl_taylor_run", "cloudsc2_ad_symmetry_run",
+            "cloudsc2_release_workspace", "cloudsc2_taylor_verdict", "cloudsc2_adjoint_verdict")
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise Cloudsc2Error(rc, (lib.cloudsc2_last_error() or b"").decode())
+
+
+def default_params(ceta=None, *, lregcl: bool = False, levapls2: bool = False, ldrain1d: bool = False) -> Params:
+    p = Params()
+    lib.cloudsc2_params_default(C.byref(p))
+    p.lregcl = int(lregcl)
+    p.levapls2 = int(levapls2)
+    p.ldrain1d = int(ldrain1d)
+    if ceta is not None:
+        p.set_ceta(ceta)
+    return p
+
+
+def device_available() -> bool:
+    return bool(lib.cloudsc2_device_available())
+
+
+def taylor_verdict(znormg) -> tuple[bool, int]:
+    z = (C.c_double * 10)(*[float(v) for v in znormg])
+    itest = C.c_int(0)
+    ok = lib.cloudsc2_taylor_verdict(z, C.byref(itest))
+    return bool(ok), int(itest.value)
+
+
+def adjoint_verdict(znormg: float) -> bool:
+    return bool(lib.cloudsc2_adjoint_verdict(float(znormg)))

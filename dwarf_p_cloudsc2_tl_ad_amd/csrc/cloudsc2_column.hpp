@@ -1,0 +1,483 @@
+// cloudsc2_column.hpp -- what one GPU lane does for its grid column: the 137-level sweeps of SATUR+CLOUDSC2,
+// CLOUDSC2TL and CLOUDSC2AD built from the per-level functions of cloudsc2_level.hpp.  The __global__ kernels in
+// cloudsc2_kernels.hip are thin wrappers (gcol = blockIdx*blockDim + threadIdx) around these functions.
+//
+// Memory access: lane g reads f[jl + NPROMA*(jk + NLEVx*ibl)] with g = ibl*NPROMA + jl, i.e. consecutive lanes
+// read consecutive doubles of every plane -> a wave64 fetches 512 contiguous bytes per plane and level.  Inputs of
+// level JK+1 are requested before level JK is evaluated (register double buffer), which is what hides HBM latency
+// at the 2-3 waves/SIMD this fp64-heavy code runs at.
+#pragma once
+#include "cloudsc2_level.hpp"
+
+#ifndef CLOUDSC2_MAX_NLEV
+#define CLOUDSC2_MAX_NLEV 200
+#endif
+
+namespace cloudsc2 {
+
+// per-level, column-independent tables (device copy)
+struct LevelTab {
+  double ceta[CLOUDSC2_MAX_NLEV];
+  double zscalm[CLOUDSC2_MAX_NLEV];
+};
+
+struct Geom {
+  int nproma, nlev, ngptot;
+  long long ncols_pad;  // NBLOCKS*NPROMA
+  int kb0, kb1;         // tropopause band [kb0,kb1): levels that can satisfy 0.1 < CETA < 0.4 (cloudsc2.F90:320)
+};
+
+// Fields are grouped by the stride between NPROMA blocks.  `full` = (NPROMA,NLEV,NBLOCKS) arrays,
+// `half` = (NPROMA,NLEV+1,NBLOCKS), `cml` = PGTEN* planes of B_CML, `clv` = PL/PI planes of PCLV,
+// `loc` = PTEN* planes of B_LOC.  The launchers check that every field of a group has the group's stride.
+struct Strides {
+  long long full, half, cml, clv, loc;
+};
+
+struct InPtrs {
+  const double *paph, *pap, *q, *qsat, *t, *l, *i, *lude, *lu, *mfu, *mfd, *gt, *gq, *gl, *gi, *supsat;
+};
+struct OutPtrs {
+  double *tent, *tenq, *tenl, *teni, *clc, *fplsl, *fplsn, *fhpsl, *fhpsn, *covptot;
+};
+struct InPtrsRW {
+  double *paph, *pap, *q, *qsat, *t, *l, *i, *lude, *lu, *mfu, *mfd, *gt, *gq, *gl, *gi, *supsat;
+};
+
+struct LaneOff {
+  long long full, half, cml, clv, loc;
+};
+
+C2_HD bool lane_setup(const Geom& g, const Strides& s, long long gcol, LaneOff& o, bool& active) {
+  if (gcol >= g.ncols_pad) return false;
+  long long ibl = gcol / g.nproma;
+  long long jl = gcol - ibl * g.nproma;
+  o.full = ibl * s.full + jl;
+  o.half = ibl * s.half + jl;
+  o.cml = ibl * s.cml + jl;
+  o.clv = ibl * s.clv + jl;
+  o.loc = ibl * s.loc + jl;
+  active = gcol < g.ngptot;
+  return true;
+}
+
+// One level's worth of raw input planes at level jk.
+struct RawLevel {
+  real_t paph, pap, q, qsat, t, l, i, lude, lu, mfu, mfd, gt, gq, gl, gi, supsat;
+};
+
+template <bool HAS_QSAT>
+C2_HD void load_raw(const InPtrs& p, const LaneOff& o, int nproma, int jk, bool full_level, RawLevel& r) {
+  const long long d = (long long)jk * nproma;
+  r.paph = p.paph[o.half + d];
+  if (full_level) {
+    r.pap = p.pap[o.full + d];
+    r.q = p.q[o.full + d];
+    r.t = p.t[o.full + d];
+    r.l = p.l[o.clv + d];
+    r.i = p.i[o.clv + d];
+    r.lude = p.lude[o.full + d];
+    r.lu = p.lu[o.full + d];
+    r.mfu = p.mfu[o.full + d];
+    r.mfd = p.mfd[o.full + d];
+    r.gt = p.gt[o.cml + d];
+    r.gq = p.gq[o.cml + d];
+    r.gl = p.gl[o.cml + d];
+    r.gi = p.gi[o.cml + d];
+    r.supsat = p.supsat[o.full + d];
+    if (HAS_QSAT) r.qsat = p.qsat[o.full + d];
+  }
+}
+
+// Perturbed state of the Taylor test: x5 = x + lambda*(0.01*x) (cloudsc_driver_tl_mod.F90:156-171,200-215).
+C2_HD real_t pert(real_t x, real_t lam) { return x + lam * (x * 0.01); }
+
+C2_HD void perturb_raw(RawLevel& r, real_t lam, bool full_level) {
+  r.paph = pert(r.paph, lam);
+  if (full_level) {
+    r.pap = pert(r.pap, lam); r.q = pert(r.q, lam); r.qsat = pert(r.qsat, lam); r.t = pert(r.t, lam);
+    r.l = pert(r.l, lam); r.i = pert(r.i, lam); r.lude = pert(r.lude, lam); r.lu = pert(r.lu, lam);
+    r.mfu = pert(r.mfu, lam); r.mfd = pert(r.mfd, lam); r.gt = pert(r.gt, lam); r.gq = pert(r.gq, lam);
+    r.gl = pert(r.gl, lam); r.gi = pert(r.gi, lam); r.supsat = pert(r.supsat, lam);
+  }
+}
+
+C2_HD void make_level_in(const RawLevel& cur, const RawLevel& nxt, real_t paph_surf, LevelIn& x) {
+  x.paph_k = cur.paph; x.paph_k1 = nxt.paph;
+  x.pap = cur.pap; x.q = cur.q; x.qs = cur.qsat; x.t = cur.t; x.l = cur.l; x.i = cur.i;
+  x.lude = cur.lude; x.lu_k1 = nxt.lu; x.mfu = cur.mfu; x.mfd = cur.mfd;
+  x.gt = cur.gt; x.gq = cur.gq; x.gl = cur.gl; x.gi = cur.gi; x.supsat = cur.supsat;
+  x.paph_surf = paph_surf;
+}
+
+// Tropopause pre-scan (cloudsc2.F90:315-326): the last band level whose first-guess T exceeds the one below.
+template <bool PERT>
+C2_HD real_t tropopause(const Consts& c, const LevelTab* tab, const InPtrs& p, const LaneOff& o, const Geom& g, real_t lam) {
+  real_t ztrpaus = 0.1;
+  if (g.kb1 > g.kb0) {
+    long long d = (long long)g.kb0 * g.nproma;
+    real_t t0 = p.t[o.full + d], g0 = p.gt[o.cml + d];
+    if (PERT) { t0 = pert(t0, lam); g0 = pert(g0, lam); }
+    real_t tup = t0 + c.ptsphy * g0;
+    for (int jk = g.kb0; jk < g.kb1; ++jk) {
+      long long d1 = (long long)(jk + 1) * g.nproma;
+      real_t t1 = p.t[o.full + d1], g1 = p.gt[o.cml + d1];
+      if (PERT) { t1 = pert(t1, lam); g1 = pert(g1, lam); }
+      real_t tdn = t1 + c.ptsphy * g1;
+      real_t ce = tab->ceta[jk];
+      if (ce > 0.1 && ce < 0.4 && tup > tdn) ztrpaus = ce;
+      tup = tdn;
+    }
+  }
+  return ztrpaus;
+}
+
+C2_HD void store_out(const OutPtrs& p, const LaneOff& o, int nproma, int jk, const Consts& c, const LevelOut& v) {
+  const long long d = (long long)jk * nproma;
+  if (p.tent) p.tent[o.loc + d] = v.tent;
+  if (p.tenq) p.tenq[o.loc + d] = v.tenq;
+  if (p.tenl) p.tenl[o.loc + d] = v.tenl;
+  if (p.teni) p.teni[o.loc + d] = v.teni;
+  if (p.clc) p.clc[o.full + d] = v.clc;
+  if (p.covptot) p.covptot[o.full + d] = v.covptot;
+  const long long d1 = d + nproma;
+  if (p.fplsl) p.fplsl[o.half + d1] = v.fplsl;
+  if (p.fplsn) p.fplsn[o.half + d1] = v.fplsn;
+  // enthalpy fluxes (cloudsc2.F90:732-733)
+  if (p.fhpsl) p.fhpsl[o.half + d1] = -v.fplsl * c.rlvtt;
+  if (p.fhpsn) p.fhpsn[o.half + d1] = -v.fplsn * c.rlstt;
+}
+
+C2_HD void store_top(const OutPtrs& p, const LaneOff& o, const Consts& c) {
+  // fluxes at the model top are zero (cloudsc2.F90:308-309); enthalpy fluxes -0*RLVTT (:732-733)
+  const real_t z = 0.0;
+  if (p.fplsl) p.fplsl[o.half] = z;
+  if (p.fplsn) p.fplsn[o.half] = z;
+  if (p.fhpsl) p.fhpsl[o.half] = -z * c.rlvtt;
+  if (p.fhpsn) p.fhpsn[o.half] = -z * c.rlstt;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// SATUR for one column
+// ---------------------------------------------------------------------------------------------------------
+C2_HD void satur_column(long long gcol, const Consts& c, const Geom& g, const Strides& s, const double* pap, const double* t,
+                        double* qsat) {
+  LaneOff o; bool active;
+  if (!lane_setup(g, s, gcol, o, active)) return;
+  if (!active) return;
+  for (int jk = 0; jk < g.nlev; ++jk) {
+    long long d = (long long)jk * g.nproma;
+    qsat[o.full + d] = satur_point(c, pap[o.full + d], t[o.full + d]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// NL: SATUR (optionally fused) + CLOUDSC2 for one column
+// ---------------------------------------------------------------------------------------------------------
+template <bool HAS_QSAT, bool PERT>
+C2_HD void nl_column(long long gcol, const Consts& c, const LevelTab* tab, const Geom& g, const Strides& s, const InPtrs& in,
+                     const OutPtrs& out, double* zero_plane, long long zero_stride, real_t lam) {
+  LaneOff o; bool active;
+  if (!lane_setup(g, s, gcol, o, active)) return;
+  long long ozero = 0;
+  if (zero_plane) {
+    long long ibl = gcol / g.nproma;
+    ozero = ibl * zero_stride + (gcol - ibl * g.nproma);
+  }
+  if (!active) {
+    // padded tail of the last block: the driver zeroes the whole block's PCOVPTOT and CLD(:,:,NCLV)
+    // (cloudsc_driver_mod.F90:87-88); nothing else is touched.
+    for (int jk = 0; jk < g.nlev; ++jk) {
+      long long d = (long long)jk * g.nproma;
+      if (out.covptot) out.covptot[o.full + d] = 0.0;
+      if (zero_plane) zero_plane[ozero + d] = 0.0;
+    }
+    return;
+  }
+
+  real_t ztrpaus = tropopause<PERT>(c, tab, in, o, g, lam);
+  RhCrit rh;
+  rhcrit_setup(ztrpaus, rh);
+
+  real_t paph_surf = 0.0;
+  if (c.evap) {
+    paph_surf = in.paph[o.half + (long long)g.nlev * g.nproma];
+    if (PERT) paph_surf = pert(paph_surf, lam);
+  }
+
+  store_top(out, o, c);
+
+  Carry cy; cy.rfl = 0.0; cy.sfl = 0.0; cy.covptot = 0.0;
+  RawLevel cur, nxt;
+  load_raw<HAS_QSAT>(in, o, g.nproma, 0, true, cur);
+  if (!HAS_QSAT) cur.qsat = satur_point(c, cur.pap, cur.t);
+  if (PERT) perturb_raw(cur, lam, true);
+
+  for (int jk = 0; jk < g.nlev; ++jk) {
+    const bool last = (jk == g.nlev - 1);
+    nxt = cur;
+    nxt.lu = 0.0;
+    load_raw<HAS_QSAT>(in, o, g.nproma, jk + 1, !last, nxt);
+    if (!last && !HAS_QSAT) nxt.qsat = satur_point(c, nxt.pap, nxt.t);
+    if (PERT) perturb_raw(nxt, lam, !last);
+
+    LevelCst k; k.ceta = tab->ceta[jk]; k.zscalm = tab->zscalm[jk]; k.last = last;
+    LevelIn x;
+    make_level_in(cur, nxt, paph_surf, x);
+    LevelTraj tr;
+    LevelOut lo;
+    level_forward(c, k, rh, x, cy, tr, lo);
+    store_out(out, o, g.nproma, jk, c, lo);
+    if (zero_plane) zero_plane[ozero + (long long)jk * g.nproma] = 0.0;
+    cur = nxt;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// TL: SATUR (optionally fused) + CLOUDSC2TL for one column
+// ---------------------------------------------------------------------------------------------------------
+template <bool HAS_QSAT>
+C2_HD void tl_column(long long gcol, const Consts& c, const LevelTab* tab, const Geom& g, const Strides& s, const Strides& sp,
+                     const InPtrs& in, const OutPtrs& out, const InPtrs& din, const OutPtrs& dout) {
+  LaneOff o, op; bool active;
+  if (!lane_setup(g, s, gcol, o, active)) return;
+  lane_setup(g, sp, gcol, op, active);
+  if (!active) return;
+
+  real_t ztrpaus = tropopause<false>(c, tab, in, o, g, 0.0);
+  RhCrit rh;
+  rhcrit_setup(ztrpaus, rh);
+
+  real_t paph_surf = 0.0, dpaph_surf = 0.0;
+  if (c.evap) {
+    paph_surf = in.paph[o.half + (long long)g.nlev * g.nproma];
+    dpaph_surf = din.paph[op.half + (long long)g.nlev * g.nproma];
+  }
+
+  store_top(out, o, c);
+  store_top(dout, op, c);
+
+  Carry cy; cy.rfl = 0.0; cy.sfl = 0.0; cy.covptot = 0.0;
+  Carry dcy; dcy.rfl = 0.0; dcy.sfl = 0.0; dcy.covptot = 0.0;
+  RawLevel cur, nxt, dcur, dnxt;
+  load_raw<HAS_QSAT>(in, o, g.nproma, 0, true, cur);
+  if (!HAS_QSAT) cur.qsat = satur_point(c, cur.pap, cur.t);
+  load_raw<true>(din, op, g.nproma, 0, true, dcur);
+
+  for (int jk = 0; jk < g.nlev; ++jk) {
+    const bool last = (jk == g.nlev - 1);
+    nxt = cur; dnxt = dcur;
+    nxt.lu = 0.0; dnxt.lu = 0.0;
+    load_raw<HAS_QSAT>(in, o, g.nproma, jk + 1, !last, nxt);
+    load_raw<true>(din, op, g.nproma, jk + 1, !last, dnxt);
+    if (!last && !HAS_QSAT) nxt.qsat = satur_point(c, nxt.pap, nxt.t);
+
+    LevelCst k; k.ceta = tab->ceta[jk]; k.zscalm = tab->zscalm[jk]; k.last = last;
+    LevelIn x, dx;
+    make_level_in(cur, nxt, paph_surf, x);
+    make_level_in(dcur, dnxt, dpaph_surf, dx);
+    LevelTraj tr;
+    LevelOut lo, dlo;
+    level_forward(c, k, rh, x, cy, tr, lo);
+    level_tl(c, k, x, tr, dx, dcy, dlo);
+    store_out(out, o, g.nproma, jk, c, lo);
+    store_out(dout, op, g.nproma, jk, c, dlo);
+    cur = nxt;
+    dcur = dnxt;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// AD for one column: forward trajectory sweep (checkpointing the three carries: rain and snow flux live in the
+// trajectory outputs PFPLSL5/PFPLSN5 that have to be written anyway, the precipitation cover goes to `scratch`),
+// then the reverse sweep re-evaluates each level's trajectory and applies the transposed level.
+// ---------------------------------------------------------------------------------------------------------
+template <bool HAS_QSAT>
+C2_HD void ad_column(long long gcol, const Consts& c, const LevelTab* tab, const Geom& g, const Strides& s, const Strides& sa,
+                     const InPtrs& in, const OutPtrs& out, const InPtrsRW& ain, const OutPtrs& aout, double* scratch) {
+  LaneOff o, oa; bool active;
+  if (!lane_setup(g, s, gcol, o, active)) return;
+  lane_setup(g, sa, gcol, oa, active);
+  if (!active) return;
+
+  // scratch: (NPROMA, NLEV, NBLOCKS) contiguous
+  const long long osc = (gcol / g.nproma) * ((long long)g.nproma * g.nlev) + (gcol % g.nproma);
+
+  real_t ztrpaus = tropopause<false>(c, tab, in, o, g, 0.0);
+  RhCrit rh;
+  rhcrit_setup(ztrpaus, rh);
+  real_t paph_surf = 0.0;
+  if (c.evap) paph_surf = in.paph[o.half + (long long)g.nlev * g.nproma];
+
+  // ---- forward sweep (cloudsc2ad.F90:366-866) ----
+  store_top(out, o, c);
+  {
+    Carry cy; cy.rfl = 0.0; cy.sfl = 0.0; cy.covptot = 0.0;
+    RawLevel cur, nxt;
+    load_raw<HAS_QSAT>(in, o, g.nproma, 0, true, cur);
+    if (!HAS_QSAT) cur.qsat = satur_point(c, cur.pap, cur.t);
+    for (int jk = 0; jk < g.nlev; ++jk) {
+      const bool last = (jk == g.nlev - 1);
+      nxt = cur;
+      nxt.lu = 0.0;
+      load_raw<HAS_QSAT>(in, o, g.nproma, jk + 1, !last, nxt);
+      if (!last && !HAS_QSAT) nxt.qsat = satur_point(c, nxt.pap, nxt.t);
+      LevelCst k; k.ceta = tab->ceta[jk]; k.zscalm = tab->zscalm[jk]; k.last = last;
+      LevelIn x;
+      make_level_in(cur, nxt, paph_surf, x);
+      scratch[osc + (long long)jk * g.nproma] = cy.covptot;  // ZCOVPTOT5(JK-1)
+      LevelTraj tr;
+      LevelOut lo;
+      level_forward(c, k, rh, x, cy, tr, lo);
+      store_out(out, o, g.nproma, jk, c, lo);
+      cur = nxt;
+    }
+  }
+
+  // ---- reverse sweep (cloudsc2ad.F90:877-1740) ----
+  Carry acy; acy.rfl = 0.0; acy.sfl = 0.0; acy.covptot = 0.0;
+  real_t paph_pending = 0.0;  // contribution of level jk+1 to the PAPHP1 adjoint at half level jk+1
+  real_t surf_acc = 0.0;      // PAPHP1(KLEV+1) adjoint, written once at the end
+  for (int jk = g.nlev - 1; jk >= 0; --jk) {
+    const bool last = (jk == g.nlev - 1);
+    const long long d = (long long)jk * g.nproma;
+    const long long d1 = d + g.nproma;
+    RawLevel cur, nxt;
+    load_raw<HAS_QSAT>(in, o, g.nproma, jk, true, cur);
+    if (!HAS_QSAT) cur.qsat = satur_point(c, cur.pap, cur.t);
+    nxt = cur;
+    nxt.paph = in.paph[o.half + d1];
+    nxt.lu = last ? 0.0 : in.lu[o.full + d1];
+    LevelCst k; k.ceta = tab->ceta[jk]; k.zscalm = tab->zscalm[jk]; k.last = last;
+    LevelIn x;
+    make_level_in(cur, nxt, paph_surf, x);
+    Carry cy;
+    cy.rfl = out.fplsl[o.half + d];  // ZRFL5(JK) = PFPLSL5(JK)
+    cy.sfl = out.fplsn[o.half + d];
+    cy.covptot = scratch[osc + d];
+    LevelTraj tr;
+    LevelOut lo;
+    level_forward(c, k, rh, x, cy, tr, lo);
+
+    // output adjoints of this level; enthalpy-flux adjoints folded in (cloudsc2ad.F90:914-921)
+    LevelOut ya;
+    ya.tent = aout.tent[oa.loc + d];
+    ya.tenq = aout.tenq[oa.loc + d];
+    ya.tenl = aout.tenl[oa.loc + d];
+    ya.teni = aout.teni[oa.loc + d];
+    ya.clc = aout.clc[oa.full + d];
+    ya.covptot = aout.covptot[oa.full + d];
+    ya.fplsn = aout.fplsn[oa.half + d1] - aout.fhpsn[oa.half + d1] * c.rlstt;
+    ya.fplsl = aout.fplsl[oa.half + d1] - aout.fhpsl[oa.half + d1] * c.rlvtt;
+
+    LevelIn ax;
+    level_ad(c, k, x, tr, ya, acy, ax);
+
+    // accumulate input adjoints (cloudsc2ad.F90:1723-1738; PSUPSAT assigned, :1733)
+    ain.pap[oa.full + d] += ax.pap;
+    ain.q[oa.full + d] += ax.q;
+    ain.qsat[oa.full + d] += ax.qs;
+    ain.t[oa.full + d] += ax.t;
+    ain.l[oa.clv + d] += ax.l;
+    ain.i[oa.clv + d] += ax.i;
+    ain.lude[oa.full + d] += ax.lude;
+    ain.mfu[oa.full + d] += ax.mfu;
+    ain.mfd[oa.full + d] += ax.mfd;
+    ain.gt[oa.cml + d] += ax.gt;
+    ain.gq[oa.cml + d] += ax.gq;
+    ain.gl[oa.cml + d] += ax.gl;
+    ain.gi[oa.cml + d] += ax.gi;
+    ain.supsat[oa.full + d] = ax.supsat;
+    if (!last) ain.lu[oa.full + d1] += ax.lu_k1;
+    surf_acc += ax.paph_surf;
+    if (last) {
+      surf_acc += ax.paph_k1;
+    } else {
+      ain.paph[oa.half + d1] += ax.paph_k1 + paph_pending;
+    }
+    paph_pending = ax.paph_k;
+
+    // output adjoints are consumed (cloudsc2ad.F90:917-919,955-966,1173,1572)
+    aout.tent[oa.loc + d] = 0.0;
+    aout.tenq[oa.loc + d] = 0.0;
+    aout.tenl[oa.loc + d] = 0.0;
+    aout.teni[oa.loc + d] = 0.0;
+    aout.clc[oa.full + d] = 0.0;
+    aout.covptot[oa.full + d] = 0.0;
+    aout.fplsl[oa.half + d1] = 0.0;
+    aout.fplsn[oa.half + d1] = 0.0;
+    aout.fhpsl[oa.half + d1] = 0.0;
+    aout.fhpsn[oa.half + d1] = 0.0;
+  }
+  ain.paph[oa.half] += paph_pending;
+  ain.paph[oa.half + (long long)g.nlev * g.nproma] += surf_acc;
+  // the adjoint of the (constant zero) top fluxes is discarded (cloudsc2ad.F90:1678-1679,917-919)
+  aout.fplsl[oa.half] = 0.0;
+  aout.fplsn[oa.half] = 0.0;
+  aout.fhpsl[oa.half] = 0.0;
+  aout.fhpsn[oa.half] = 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Adjoint-test norms per column (cloudsc_driver_ad_mod.F90:184-195,240-264)
+// ---------------------------------------------------------------------------------------------------------
+// norm1 = <y,y>, field by field like the reference's SUMs (:185-194)
+C2_HD double adjoint_norm1_column(const Geom& g, const LaneOff& oa, const OutPtrs& y) {
+  double st = 0, sq = 0, sl = 0, si = 0, sc = 0, sfl = 0, sfn = 0, shl = 0, shn = 0, scv = 0;
+  for (int jk = 0; jk < g.nlev; ++jk) {
+    long long d = (long long)jk * g.nproma;
+    double v;
+    v = y.tent[oa.loc + d]; st += v * v;
+    v = y.tenq[oa.loc + d]; sq += v * v;
+    v = y.tenl[oa.loc + d]; sl += v * v;
+    v = y.teni[oa.loc + d]; si += v * v;
+    v = y.clc[oa.full + d]; sc += v * v;
+    v = y.covptot[oa.full + d]; scv += v * v;
+  }
+  for (int jk = 0; jk <= g.nlev; ++jk) {
+    long long d = (long long)jk * g.nproma;
+    double v;
+    v = y.fplsl[oa.half + d]; sfl += v * v;
+    v = y.fplsn[oa.half + d]; sfn += v * v;
+    v = y.fhpsl[oa.half + d]; shl += v * v;
+    v = y.fhpsn[oa.half + d]; shn += v * v;
+  }
+  return st + sq + sl + si + sc + sfl + sfn + shl + shn + scv;
+}
+
+// norm2 = <x0, x_adj> with x0 = 0.01 * trajectory inputs; ZSUPSAT0 = 0 (:139,157) so that term vanishes
+C2_HD double adjoint_norm2_column(const Geom& g, const LaneOff& o, const LaneOff& oa, long long oq, const InPtrs& in,
+                                  const double* qsat, const InPtrs& xa) {
+  double s_aph = 0, s_ap = 0, s_q = 0, s_qs = 0, s_t = 0, s_l = 0, s_i = 0, s_lude = 0, s_lu = 0, s_mfu = 0, s_mfd = 0, s_gt = 0,
+         s_gq = 0, s_gl = 0, s_gi = 0;
+  for (int jk = 0; jk <= g.nlev; ++jk) {
+    long long d = (long long)jk * g.nproma;
+    s_aph += (in.paph[o.half + d] * 0.01) * xa.paph[oa.half + d];
+  }
+  for (int jk = 0; jk < g.nlev; ++jk) {
+    long long d = (long long)jk * g.nproma;
+    s_ap += (in.pap[o.full + d] * 0.01) * xa.pap[oa.full + d];
+    s_q += (in.q[o.full + d] * 0.01) * xa.q[oa.full + d];
+    s_qs += (qsat[oq + d] * 0.01) * xa.qsat[oa.full + d];
+    s_t += (in.t[o.full + d] * 0.01) * xa.t[oa.full + d];
+    s_l += (in.l[o.clv + d] * 0.01) * xa.l[oa.clv + d];
+    s_i += (in.i[o.clv + d] * 0.01) * xa.i[oa.clv + d];
+    s_lude += (in.lude[o.full + d] * 0.01) * xa.lude[oa.full + d];
+    s_lu += (in.lu[o.full + d] * 0.01) * xa.lu[oa.full + d];
+    s_mfu += (in.mfu[o.full + d] * 0.01) * xa.mfu[oa.full + d];
+    s_mfd += (in.mfd[o.full + d] * 0.01) * xa.mfd[oa.full + d];
+    s_gt += (in.gt[o.cml + d] * 0.01) * xa.gt[oa.cml + d];
+    s_gq += (in.gq[o.cml + d] * 0.01) * xa.gq[oa.cml + d];
+    s_gl += (in.gl[o.cml + d] * 0.01) * xa.gl[oa.cml + d];
+    s_gi += (in.gi[o.cml + d] * 0.01) * xa.gi[oa.cml + d];
+  }
+  return s_aph + s_ap + s_q + s_qs + s_t + s_l + s_i + s_lude + s_lu + s_mfu + s_mfd + s_gt + s_gq + s_gl + s_gi + 0.0;
+}
+
+C2_HD double adjoint_norm3(double n1, double n2) {
+  const double eps = 2.220446049250313e-16;  // EPSILON(1._8)
+  if (n2 == 0.0) return fabs(n1 - n2) / eps;
+  return fabs(n1 - n2) / eps / n2;
+}
+
+}  // namespace cloudsc2

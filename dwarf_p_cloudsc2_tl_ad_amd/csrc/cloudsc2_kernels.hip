@@ -1,0 +1,567 @@
+// cloudsc2_kernels.hip -- gfx950 kernels + C ABI (include/cloudsc2_hip.h) of the CLOUDSC2 NL/TL/AD engine.
+//
+// Mapping: one lane = one grid column, lanes run over the global column index g = ibl*NPROMA + jl of the
+// reference's (NPROMA, NLEV, NBLOCKS) layout, so a wave64 reads 64 consecutive doubles (512 B) of every
+// input plane per level: fully coalesced for any NPROMA (for NPROMA in {64,128,256} and blockDim = NPROMA one
+// thread block is exactly one NPROMA block).  The 137-level sweep is sequential per lane with three carried
+// scalars; inputs of level JK+1 are requested before level JK is computed (register double buffer).
+// There is no MFMA (pointwise physics) and no inter-lane traffic in the kernels proper; wave/LDS reductions
+// appear only in the two test-norm kernels.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/cloudsc2_hip.h"
+#include "cloudsc2_column.hpp"
+
+using namespace cloudsc2;
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------
+// error handling
+// ---------------------------------------------------------------------------------------------------------
+thread_local std::string g_err;
+
+int fail(int code, const char* msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                     \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess) {                                                               \
+      g_err = std::string(#expr) + ": " + hipGetErrorString(e_);                          \
+      return (int)e_;                                                                     \
+    }                                                                                     \
+  } while (0)
+
+bool device_ok() {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+  return n > 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// launch-invariant constants and per-level tables
+// ---------------------------------------------------------------------------------------------------------
+Consts make_consts(const cloudsc2_params& p, double ptsphy) {
+  Consts c;
+  c.rg = p.rg; c.rd = p.rd; c.rcpd = p.rcpd; c.retv = p.retv; c.rlvtt = p.rlvtt; c.rlstt = p.rlstt;
+  c.rlmlt = p.rlmlt; c.rtt = p.rtt;
+  c.r2es = p.r2es; c.r3les = p.r3les; c.r3ies = p.r3ies; c.r4les = p.r4les; c.r4ies = p.r4ies;
+  c.r5les = p.r5les; c.r5ies = p.r5ies; c.r5alvcp = p.r5alvcp; c.r5alscp = p.r5alscp;
+  c.ralvdcp = p.ralvdcp; c.ralsdcp = p.ralsdcp;
+  c.rtwat = p.rtwat; c.rtice = p.rtice; c.rtwat_rtice_r = p.rtwat_rtice_r; c.rvtmp2 = p.rvtmp2;
+  c.rlmin = p.rlmin; c.rpecons = p.rpecons; c.rlptrc = p.rlptrc;
+  c.ptsphy = ptsphy;
+  // cloudsc2.F90:235-240, cloudsc2tl.F90:321-328
+  c.zckcodtl = 2.0 * p.rkconv * ptsphy;
+  c.zckcodti = 5.0 * p.rkconv * ptsphy;
+  c.zckcodtla = c.zckcodtl / 100.0;
+  c.zckcodtia = c.zckcodti / 100.0;
+  c.zcons2 = 1.0 / (ptsphy * p.rg);
+  c.zcons3 = p.rlvtt / p.rcpd;
+  c.zmeltp2 = p.rtt + 2.0;
+  c.zqtmst = 1.0 / ptsphy;
+  c.evap = (p.levapls2 || p.ldrain1d) ? 1 : 0;
+  // cloudsc2.F90:505-509,522-526
+  c.zlcrit_l = c.evap ? 1.9 * p.rclcrit : p.rclcrit * 2.0;
+  c.zlcrit_i = c.evap ? 1.e-04 : p.rclcrit * 2.0;
+  c.rcpd_r = 1.0 / p.rcpd;
+  c.rvtmp2_zero = (p.rvtmp2 == 0.0) ? 1 : 0;
+  c.zzz0 = 1.0 / (p.rcpd + p.rcpd * p.rvtmp2 * 0.0);
+  c.lregcl = p.lregcl ? 1 : 0;
+  c.nlev = p.nlev;
+  return c;
+}
+
+// Device copies of the level tables are immutable once created and keyed by content, so launches on
+// different streams never race on them.
+struct TabEntry {
+  int device;
+  int nlev;
+  std::vector<double> ceta;
+  LevelTab* dev;
+  int kb0, kb1;  // tropopause band: levels jk (0-based) in [kb0,kb1) can have 0.1 < ceta < 0.4 and jk < nlev-1
+};
+std::mutex g_tab_mutex;
+std::vector<TabEntry> g_tabs;
+
+int get_tables(const cloudsc2_params& p, const LevelTab** dev, int* kb0, int* kb1) {
+  int device = 0;
+  HIP_TRY(hipGetDevice(&device));
+  std::lock_guard<std::mutex> lock(g_tab_mutex);
+  for (auto& e : g_tabs) {
+    if (e.device == device && e.nlev == p.nlev && memcmp(e.ceta.data(), p.ceta, sizeof(double) * p.nlev) == 0) {
+      *dev = e.dev; *kb0 = e.kb0; *kb1 = e.kb1;
+      return 0;
+    }
+  }
+  TabEntry e;
+  e.device = device;
+  e.nlev = p.nlev;
+  e.ceta.assign(p.ceta, p.ceta + p.nlev);
+  LevelTab host;
+  memset(&host, 0, sizeof(host));
+  e.kb0 = p.nlev; e.kb1 = 0;
+  for (int jk = 0; jk < p.nlev; ++jk) {
+    host.ceta[jk] = p.ceta[jk];
+    // cloudsc2.F90:266  ZSCALM(JK)=ZSCAL*MAX((CETA(JK)-0.2),ZEPS1)**0.2, ZSCAL=0.9 (:172)
+    host.zscalm[jk] = 0.9 * pow(fmax(p.ceta[jk] - 0.2, 1.e-12), 0.2);
+    if (jk < p.nlev - 1 && p.ceta[jk] > 0.1 && p.ceta[jk] < 0.4) {  // cloudsc2.F90:318-321
+      if (jk < e.kb0) e.kb0 = jk;
+      if (jk + 1 > e.kb1) e.kb1 = jk + 1;
+    }
+  }
+  if (e.kb1 <= e.kb0) { e.kb0 = 0; e.kb1 = 0; }
+  HIP_TRY(hipMalloc((void**)&e.dev, sizeof(LevelTab)));
+  HIP_TRY(hipMemcpy(e.dev, &host, sizeof(LevelTab), hipMemcpyHostToDevice));
+  g_tabs.push_back(e);
+  *dev = e.dev; *kb0 = e.kb0; *kb1 = e.kb1;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// kernels: thin wrappers around the per-column functions of cloudsc2_column.hpp
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kBlock = 128;
+
+__device__ __forceinline__ long long global_column() { return (long long)blockIdx.x * blockDim.x + threadIdx.x; }
+
+__global__ void __launch_bounds__(kBlock) satur_kernel(Consts c, Geom g, Strides s, const double* pap, const double* t,
+                                                       double* qsat) {
+  satur_column(global_column(), c, g, s, pap, t, qsat);
+}
+
+template <bool HAS_QSAT, bool PERT>
+__global__ void __launch_bounds__(kBlock)
+nl_kernel(Consts c, const LevelTab* __restrict__ tab, Geom g, Strides s, InPtrs in, OutPtrs out, double* zero_plane,
+          long long zero_stride, real_t lam) {
+  nl_column<HAS_QSAT, PERT>(global_column(), c, tab, g, s, in, out, zero_plane, zero_stride, lam);
+}
+
+template <bool HAS_QSAT>
+__global__ void __launch_bounds__(kBlock)
+tl_kernel(Consts c, const LevelTab* __restrict__ tab, Geom g, Strides s, Strides sp, InPtrs in, OutPtrs out, InPtrs din,
+          OutPtrs dout) {
+  tl_column<HAS_QSAT>(global_column(), c, tab, g, s, sp, in, out, din, dout);
+}
+
+template <bool HAS_QSAT>
+__global__ void __launch_bounds__(kBlock)
+ad_kernel(Consts c, const LevelTab* __restrict__ tab, Geom g, Strides s, Strides sa, InPtrs in, OutPtrs out, InPtrsRW ain,
+          OutPtrs aout, double* __restrict__ scratch) {
+  ad_column<HAS_QSAT>(global_column(), c, tab, g, s, sa, in, out, ain, aout, scratch);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Test-norm kernels
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+  return v;
+}
+
+// ERROR_NORM sums (cloudsc_driver_tl_mod.F90:21-31): one thread block per NPROMA block, lanes stride the
+// block's active columns, per-lane level sums, wave shuffles, then one LDS stage.
+// sums[(ibl*10 + f)*2 + {0,1}] = { sum(F - F5), sum(TL*lambda) }.
+struct TenPtrs { const double* p[10]; long long stride[10]; int nlevx[10]; };
+
+__global__ void __launch_bounds__(256) taylor_sums_kernel(int nproma, int nlev, int ngptot, TenPtrs f, TenPtrs f5, TenPtrs tl,
+                                                          double lambda, double* sums) {
+  (void)nlev;
+  const int ibl = blockIdx.x;
+  const int icend = min(nproma, ngptot - ibl * nproma);
+  __shared__ double red[2][4];
+  for (int fi = 0; fi < 10; ++fi) {
+    double s0 = 0.0, s1 = 0.0;
+    const double* a = f.p[fi] + (long long)ibl * f.stride[fi];
+    const double* b = f5.p[fi] + (long long)ibl * f5.stride[fi];
+    const double* t = tl.p[fi] + (long long)ibl * tl.stride[fi];
+    const int nl = f.nlevx[fi];
+    for (int jl = threadIdx.x; jl < icend; jl += blockDim.x) {
+      for (int jk = 0; jk < nl; ++jk) {
+        long long d = (long long)jk * nproma + jl;
+        s0 += a[d] - b[d];
+        s1 += t[d] * lambda;
+      }
+    }
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][w] = s0; red[1][w] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double r0 = 0.0, r1 = 0.0;
+      for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { r0 += red[0][i]; r1 += red[1][i]; }
+      sums[((long long)ibl * 10 + fi) * 2 + 0] = r0;
+      sums[((long long)ibl * 10 + fi) * 2 + 1] = r1;
+    }
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ void atomic_max_pos(double* addr, double v) {
+  // v >= 0: the IEEE bit pattern of non-negative doubles orders like unsigned integers
+  atomicMax((unsigned long long*)addr, (unsigned long long)__double_as_longlong(v));
+}
+
+// Adjoint-test norms (cloudsc_driver_ad_mod.F90:184-195,240-264): lane = column, level sums in registers
+// (cloudsc2_column.hpp), wave max by shuffles, one atomic max per wave.
+__global__ void __launch_bounds__(kBlock) adjoint_norm1_kernel(Geom g, Strides sa, OutPtrs y, double* norms) {
+  long long gcol = global_column();
+  LaneOff oa; bool active;
+  if (!lane_setup(g, sa, gcol, oa, active) || !active) return;
+  norms[gcol] = adjoint_norm1_column(g, oa, y);
+}
+
+__global__ void __launch_bounds__(kBlock)
+adjoint_norm2_kernel(Geom g, Strides s, Strides sa, InPtrs in, const double* qsat, long long qsat_stride, InPtrs xa,
+                     double* norms, long long ncols_pad, double* gmax) {
+  long long gcol = global_column();
+  LaneOff o, oa; bool active;
+  double n3 = 0.0;
+  if (lane_setup(g, s, gcol, o, active) && active) {
+    lane_setup(g, sa, gcol, oa, active);
+    const long long oq = (gcol / g.nproma) * qsat_stride + (gcol % g.nproma);
+    double n2 = adjoint_norm2_column(g, o, oa, oq, in, qsat, xa);
+    double n1 = norms[gcol];
+    n3 = adjoint_norm3(n1, n2);
+    norms[ncols_pad + gcol] = n2;
+    norms[2 * ncols_pad + gcol] = n3;
+    n3 = fabs(n3);
+    if (!(n3 == n3)) n3 = __longlong_as_double(0x7ff0000000000000LL);  // NaN counts as failure (+inf)
+  }
+  double m = wave_max(n3);
+  if ((threadIdx.x & 63) == 0) atomic_max_pos(gmax, m);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host-side helpers for the launchers
+// ---------------------------------------------------------------------------------------------------------
+struct GroupStride {
+  long long v;
+  bool set;
+  bool ok;
+  GroupStride() : v(0), set(false), ok(true) {}
+  void add(const cloudsc2_field& f) {
+    if (!f.ptr) return;
+    if (!set) { v = f.block_stride; set = true; }
+    else if (v != f.block_stride) ok = false;
+  }
+};
+
+int resolve_in(const cloudsc2_inputs& in, bool need_qsat, Strides& s, InPtrs& p) {
+  const cloudsc2_field* req[] = {&in.paph, &in.pap, &in.q, &in.t, &in.l, &in.i, &in.lude, &in.lu,
+                                 &in.mfu,  &in.mfd, &in.gtent, &in.gtenq, &in.gtenl, &in.gteni, &in.supsat};
+  for (auto f : req)
+    if (!f->ptr) return fail(CLOUDSC2_EINVAL, "a required input field has a NULL pointer");
+  if (need_qsat && !in.qsat.ptr) return fail(CLOUDSC2_EINVAL, "qsat field required");
+  GroupStride full, half, cml, clv;
+  full.add(in.pap); full.add(in.q); full.add(in.qsat); full.add(in.t); full.add(in.lude); full.add(in.lu);
+  full.add(in.mfu); full.add(in.mfd); full.add(in.supsat);
+  half.add(in.paph);
+  cml.add(in.gtent); cml.add(in.gtenq); cml.add(in.gtenl); cml.add(in.gteni);
+  clv.add(in.l); clv.add(in.i);
+  if (!full.ok || !half.ok || !cml.ok || !clv.ok)
+    return fail(CLOUDSC2_EINVAL, "fields of one layout group (full-level / PGTEN* / PL,PI) must share one block stride");
+  s.full = full.v; s.half = half.v; s.cml = cml.v; s.clv = clv.v;
+  p.paph = in.paph.ptr; p.pap = in.pap.ptr; p.q = in.q.ptr; p.qsat = in.qsat.ptr; p.t = in.t.ptr; p.l = in.l.ptr;
+  p.i = in.i.ptr; p.lude = in.lude.ptr; p.lu = in.lu.ptr; p.mfu = in.mfu.ptr; p.mfd = in.mfd.ptr;
+  p.gt = in.gtent.ptr; p.gq = in.gtenq.ptr; p.gl = in.gtenl.ptr; p.gi = in.gteni.ptr; p.supsat = in.supsat.ptr;
+  return 0;
+}
+
+int resolve_out(const cloudsc2_outputs& out, bool all_required, Strides& s, OutPtrs& p) {
+  const cloudsc2_field* all[] = {&out.tent, &out.tenq, &out.tenl, &out.teni, &out.clc,
+                                 &out.fplsl, &out.fplsn, &out.fhpsl, &out.fhpsn, &out.covptot};
+  if (all_required)
+    for (auto f : all)
+      if (!f->ptr) return fail(CLOUDSC2_EINVAL, "a required output field has a NULL pointer");
+  GroupStride full, half, loc;
+  full.add(out.clc); full.add(out.covptot);
+  half.add(out.fplsl); half.add(out.fplsn); half.add(out.fhpsl); half.add(out.fhpsn);
+  loc.add(out.tent); loc.add(out.tenq); loc.add(out.tenl); loc.add(out.teni);
+  if (!full.ok || !half.ok || !loc.ok)
+    return fail(CLOUDSC2_EINVAL, "output fields of one layout group must share one block stride");
+  if (full.set) { if (s.full && s.full != full.v) return fail(CLOUDSC2_EINVAL, "PCLC/PCOVPTOT stride differs from the input full-level stride"); s.full = full.v; }
+  if (half.set) { if (s.half && s.half != half.v) return fail(CLOUDSC2_EINVAL, "flux stride differs from the PAPH stride"); s.half = half.v; }
+  s.loc = loc.v;
+  p.tent = out.tent.ptr; p.tenq = out.tenq.ptr; p.tenl = out.tenl.ptr; p.teni = out.teni.ptr; p.clc = out.clc.ptr;
+  p.fplsl = out.fplsl.ptr; p.fplsn = out.fplsn.ptr; p.fhpsl = out.fhpsl.ptr; p.fhpsn = out.fhpsn.ptr;
+  p.covptot = out.covptot.ptr;
+  return 0;
+}
+
+int check_geom(const cloudsc2_params* prm, int nproma, int nlev, int ngptot, Geom& g) {
+  if (!prm) return fail(CLOUDSC2_EINVAL, "params is NULL");
+  if (nproma < 1 || nlev < 2 || ngptot < 1) return fail(CLOUDSC2_EINVAL, "nproma >= 1, nlev >= 2, ngptot >= 1 required");
+  if (nlev > CLOUDSC2_MAX_NLEV) return fail(CLOUDSC2_EINVAL, "nlev exceeds CLOUDSC2_MAX_NLEV");
+  if (prm->nlev != nlev) return fail(CLOUDSC2_EINVAL, "params.nlev does not match nlev");
+  if (!prm->lphylin) return fail(CLOUDSC2_EINVAL, "LPHYLIN=.false. is not supported (every reference main forces .true.)");
+  if (!device_ok()) return fail(CLOUDSC2_ENODEVICE, "no HIP device available (this library has no CPU path)");
+  long long nblocks = ((long long)ngptot + nproma - 1) / nproma;
+  g.nproma = nproma; g.nlev = nlev; g.ngptot = ngptot; g.ncols_pad = nblocks * nproma;
+  g.kb0 = 0; g.kb1 = 0;
+  return 0;
+}
+
+inline unsigned grid_for(long long ncols, int block) { return (unsigned)((ncols + block - 1) / block); }
+
+}  // namespace
+
+// =========================================================================================================
+// C ABI
+// =========================================================================================================
+extern "C" {
+
+const char* cloudsc2_last_error(void) { return g_err.c_str(); }
+
+int cloudsc2_device_available(void) { return device_ok() ? 1 : 0; }
+
+void cloudsc2_params_default(cloudsc2_params* p) {
+  memset(p, 0, sizeof(*p));
+  // standard IFS values; only RLSTT is confirmed by config-files/reference.h5
+  p->rg = 9.80665;
+  p->rd = 287.0597;
+  const double rv = 461.5250;
+  p->rcpd = 3.5 * p->rd;
+  p->retv = rv / p->rd - 1.0;
+  p->rlvtt = 2.5008e6;
+  p->rlstt = 2.8345e6;
+  p->rlmlt = p->rlstt - p->rlvtt;
+  p->rtt = 273.16;
+  p->r2es = 611.21 * p->rd / rv;
+  p->r3les = 17.502;
+  p->r3ies = 22.587;
+  p->r4les = 32.19;
+  p->r4ies = -0.7;
+  p->r5les = p->r3les * (p->rtt - p->r4les);
+  p->r5ies = p->r3ies * (p->rtt - p->r4ies);
+  p->r5alvcp = p->r5les * p->rlvtt / p->rcpd;
+  p->r5alscp = p->r5ies * p->rlstt / p->rcpd;
+  p->ralvdcp = p->rlvtt / p->rcpd;
+  p->ralsdcp = p->rlstt / p->rcpd;
+  p->rtwat = p->rtt;
+  p->rtice = p->rtt - 23.0;
+  p->rtwat_rtice_r = 1.0 / (p->rtwat - p->rtice);
+  p->rvtmp2 = 0.0;
+  p->rclcrit = 0.4e-3;
+  p->rkconv = 1.0 / 6000.0;
+  p->rlmin = 1.e-8;
+  p->rpecons = 5.547e-5;
+  p->rlptrc = p->rtice + (p->rtwat - p->rtice) / sqrt(2.0);
+  p->rticecu = p->rtt - 23.0;
+  p->rtwat_rticecu_r = 1.0 / (p->rtwat - p->rticecu);
+  p->lphylin = 1;
+  p->levapls2 = 0;
+  p->lregcl = 0;
+  p->ldrain1d = 0;
+  p->nlev = 0;
+}
+
+int cloudsc2_satur_launch(const cloudsc2_params* prm, int nproma, int nlev, int ngptot, cloudsc2_field pap,
+                          cloudsc2_field t, cloudsc2_field qsat, void* stream) {
+  Geom g;
+  int rc = check_geom(prm, nproma, nlev, ngptot, g);
+  if (rc) return rc;
+  if (!pap.ptr || !t.ptr || !qsat.ptr) return fail(CLOUDSC2_EINVAL, "NULL field");
+  if (pap.block_stride != t.block_stride || pap.block_stride != qsat.block_stride)
+    return fail(CLOUDSC2_EINVAL, "pap, t, qsat must share one block stride");
+  Strides s = {pap.block_stride, 0, 0, 0, 0};
+  Consts c = make_consts(*prm, 1.0);
+  hipLaunchKernelGGL(satur_kernel, dim3(grid_for(g.ncols_pad, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, c, g, s,
+                     (const double*)pap.ptr, (const double*)t.ptr, qsat.ptr);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int cloudsc2_nl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
+                       const cloudsc2_inputs* in, const cloudsc2_outputs* out, cloudsc2_field zero_plane,
+                       double pert_lambda, void* stream) {
+  Geom g;
+  int rc = check_geom(prm, nproma, nlev, ngptot, g);
+  if (rc) return rc;
+  if (!in || !out) return fail(CLOUDSC2_EINVAL, "NULL argument block");
+  Strides s = {0, 0, 0, 0, 0};
+  InPtrs ip; OutPtrs op;
+  if ((rc = resolve_in(*in, false, s, ip))) return rc;
+  if ((rc = resolve_out(*out, false, s, op))) return rc;
+  const LevelTab* tab;
+  if ((rc = get_tables(*prm, &tab, &g.kb0, &g.kb1))) return rc;
+  Consts c = make_consts(*prm, ptsphy);
+  dim3 grid(grid_for(g.ncols_pad, kBlock)), block(kBlock);
+  hipStream_t st = (hipStream_t)stream;
+  const bool has_qsat = in->qsat.ptr != nullptr;
+  const bool pertb = pert_lambda != 0.0;
+#define C2_NL(HQ, PT)                                                                                          \
+  hipLaunchKernelGGL((nl_kernel<HQ, PT>), grid, block, 0, st, c, tab, g, s, ip, op, zero_plane.ptr,            \
+                     zero_plane.block_stride, pert_lambda)
+  if (has_qsat && pertb) C2_NL(true, true);
+  else if (has_qsat) C2_NL(true, false);
+  else if (pertb) C2_NL(false, true);
+  else C2_NL(false, false);
+#undef C2_NL
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int cloudsc2_tl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
+                       const cloudsc2_inputs* traj_in, const cloudsc2_outputs* traj_out,
+                       const cloudsc2_inputs* pert_in, const cloudsc2_outputs* pert_out, void* stream) {
+  Geom g;
+  int rc = check_geom(prm, nproma, nlev, ngptot, g);
+  if (rc) return rc;
+  if (!traj_in || !traj_out || !pert_in || !pert_out) return fail(CLOUDSC2_EINVAL, "NULL argument block");
+  Strides s = {0, 0, 0, 0, 0}, sp = {0, 0, 0, 0, 0};
+  InPtrs ip, dip; OutPtrs op, dop;
+  if ((rc = resolve_in(*traj_in, false, s, ip))) return rc;
+  if ((rc = resolve_out(*traj_out, false, s, op))) return rc;
+  if ((rc = resolve_in(*pert_in, true, sp, dip))) return rc;
+  if ((rc = resolve_out(*pert_out, true, sp, dop))) return rc;
+  const LevelTab* tab;
+  if ((rc = get_tables(*prm, &tab, &g.kb0, &g.kb1))) return rc;
+  Consts c = make_consts(*prm, ptsphy);
+  dim3 grid(grid_for(g.ncols_pad, kBlock)), block(kBlock);
+  hipStream_t st = (hipStream_t)stream;
+  if (traj_in->qsat.ptr) hipLaunchKernelGGL((tl_kernel<true>), grid, block, 0, st, c, tab, g, s, sp, ip, op, dip, dop);
+  else hipLaunchKernelGGL((tl_kernel<false>), grid, block, 0, st, c, tab, g, s, sp, ip, op, dip, dop);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int cloudsc2_ad_launch(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
+                       const cloudsc2_inputs* traj_in, const cloudsc2_outputs* traj_out,
+                       const cloudsc2_inputs* adj_in, const cloudsc2_outputs* adj_out, double* scratch,
+                       void* stream) {
+  Geom g;
+  int rc = check_geom(prm, nproma, nlev, ngptot, g);
+  if (rc) return rc;
+  if (!traj_in || !traj_out || !adj_in || !adj_out || !scratch) return fail(CLOUDSC2_EINVAL, "NULL argument block");
+  Strides s = {0, 0, 0, 0, 0}, sa = {0, 0, 0, 0, 0};
+  InPtrs ip, aip_c; OutPtrs op, aop;
+  if ((rc = resolve_in(*traj_in, false, s, ip))) return rc;
+  if ((rc = resolve_out(*traj_out, true, s, op))) return rc;
+  if ((rc = resolve_in(*adj_in, true, sa, aip_c))) return rc;
+  if ((rc = resolve_out(*adj_out, true, sa, aop))) return rc;
+  InPtrsRW aip;
+  aip.paph = adj_in->paph.ptr; aip.pap = adj_in->pap.ptr; aip.q = adj_in->q.ptr; aip.qsat = adj_in->qsat.ptr;
+  aip.t = adj_in->t.ptr; aip.l = adj_in->l.ptr; aip.i = adj_in->i.ptr; aip.lude = adj_in->lude.ptr;
+  aip.lu = adj_in->lu.ptr; aip.mfu = adj_in->mfu.ptr; aip.mfd = adj_in->mfd.ptr; aip.gt = adj_in->gtent.ptr;
+  aip.gq = adj_in->gtenq.ptr; aip.gl = adj_in->gtenl.ptr; aip.gi = adj_in->gteni.ptr; aip.supsat = adj_in->supsat.ptr;
+  const LevelTab* tab;
+  if ((rc = get_tables(*prm, &tab, &g.kb0, &g.kb1))) return rc;
+  Consts c = make_consts(*prm, ptsphy);
+  dim3 grid(grid_for(g.ncols_pad, kBlock)), block(kBlock);
+  hipStream_t st = (hipStream_t)stream;
+  if (traj_in->qsat.ptr) hipLaunchKernelGGL((ad_kernel<true>), grid, block, 0, st, c, tab, g, s, sa, ip, op, aip, aop, scratch);
+  else hipLaunchKernelGGL((ad_kernel<false>), grid, block, 0, st, c, tab, g, s, sa, ip, op, aip, aop, scratch);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+static int ten_ptrs(const cloudsc2_outputs* o, int nlev, TenPtrs& t) {
+  // order of the ERROR_NORM calls, cloudsc_driver_tl_mod.F90:233-242
+  const cloudsc2_field* f[10] = {&o->tent, &o->tenq, &o->tenl, &o->teni, &o->clc,
+                                 &o->fplsl, &o->fplsn, &o->fhpsl, &o->fhpsn, &o->covptot};
+  const int half[10] = {0, 0, 0, 0, 0, 1, 1, 1, 1, 0};
+  for (int i = 0; i < 10; ++i) {
+    if (!f[i]->ptr) return fail(CLOUDSC2_EINVAL, "taylor sums: NULL field");
+    t.p[i] = f[i]->ptr; t.stride[i] = f[i]->block_stride; t.nlevx[i] = nlev + half[i];
+  }
+  return 0;
+}
+
+int cloudsc2_taylor_sums_launch(int nproma, int nlev, int ngptot, const cloudsc2_outputs* f,
+                                const cloudsc2_outputs* f_pert, const cloudsc2_outputs* tl, double lambda,
+                                double* sums, void* stream) {
+  if (!f || !f_pert || !tl || !sums) return fail(CLOUDSC2_EINVAL, "NULL argument");
+  if (!device_ok()) return fail(CLOUDSC2_ENODEVICE, "no HIP device available (this library has no CPU path)");
+  TenPtrs a, b, c;
+  int rc;
+  if ((rc = ten_ptrs(f, nlev, a))) return rc;
+  if ((rc = ten_ptrs(f_pert, nlev, b))) return rc;
+  if ((rc = ten_ptrs(tl, nlev, c))) return rc;
+  int nblocks = (ngptot + nproma - 1) / nproma;
+  hipLaunchKernelGGL(taylor_sums_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, nproma, nlev, ngptot, a, b, c,
+                     lambda, sums);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int cloudsc2_adjoint_norms_launch(int nproma, int nlev, int ngptot, const cloudsc2_inputs* traj_in,
+                                  const cloudsc2_field* qsat, const cloudsc2_outputs* y,
+                                  const cloudsc2_inputs* x_adj, double* norms, double* blockmax, void* stream) {
+  // y == NULL: second half only (norm2/norm3 from norm1 already in norms); x_adj == NULL: first half only.
+  if (!norms) return fail(CLOUDSC2_EINVAL, "NULL argument");
+  if (!device_ok()) return fail(CLOUDSC2_ENODEVICE, "no HIP device available (this library has no CPU path)");
+  Geom g;
+  long long nblocks = ((long long)ngptot + nproma - 1) / nproma;
+  g.nproma = nproma; g.nlev = nlev; g.ngptot = ngptot; g.ncols_pad = nblocks * nproma; g.kb0 = g.kb1 = 0;
+  dim3 grid(grid_for(g.ncols_pad, kBlock)), block(kBlock);
+  int rc;
+  if (y) {
+    Strides sa = {0, 0, 0, 0, 0};
+    OutPtrs yp;
+    if ((rc = resolve_out(*y, true, sa, yp))) return rc;
+    hipLaunchKernelGGL(adjoint_norm1_kernel, grid, block, 0, (hipStream_t)stream, g, sa, yp, norms);
+    HIP_TRY(hipGetLastError());
+  }
+  if (x_adj) {
+    if (!traj_in || !qsat || !qsat->ptr || !blockmax) return fail(CLOUDSC2_EINVAL, "NULL argument");
+    Strides s = {0, 0, 0, 0, 0}, sa = {0, 0, 0, 0, 0};
+    InPtrs ip, xp;
+    if ((rc = resolve_in(*traj_in, false, s, ip))) return rc;
+    if ((rc = resolve_in(*x_adj, true, sa, xp))) return rc;
+    hipLaunchKernelGGL(adjoint_norm2_kernel, grid, block, 0, (hipStream_t)stream, g, s, sa, ip, (const double*)qsat->ptr,
+                       qsat->block_stride, xp, norms, g.ncols_pad, blockmax);
+    HIP_TRY(hipGetLastError());
+  }
+  return 0;
+}
+
+int cloudsc2_taylor_verdict(const double znormg_in[10], int* itest_out) {
+  // cloudsc_driver_tl_mod.F90:272-311
+  double z[10];
+  int istart = 0;
+  for (int i = 0; i < 10; ++i) {
+    z[i] = fabs(1.0 - znormg_in[i]);
+    if (istart == 0 && z[i] < 0.5) istart = i + 1;
+  }
+  if (istart == 0 || istart > 4) {
+    if (itest_out) *itest_out = 13;
+    return 0;
+  }
+  int itest = -10, inegat = 1;
+  for (int il = istart; il <= 9; ++il) {
+    int itemp = (z[il] / z[il - 1] < 1.0) ? 1 : 0;
+    if (inegat > itemp) itest += 10;
+    inegat = itemp;
+  }
+  if (itest == -10) itest = 11;
+  double mn = z[istart - 1];
+  for (int i = istart - 1; i < 10; ++i) mn = fmin(mn, z[i]);
+  if (mn > 0.00001) itest += 7;
+  if (mn > 0.000001) itest += 5;
+  if (itest_out) *itest_out = itest;
+  return itest > 5 ? 0 : 1;
+}
+
+int cloudsc2_adjoint_verdict(double znormg) { return (znormg < 10000.0) ? 1 : 0; }
+
+}  // extern "C"
+
+#include "cloudsc2_driver.inc"

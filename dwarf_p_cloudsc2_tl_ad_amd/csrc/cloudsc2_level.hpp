@@ -1,0 +1,1076 @@
+// cloudsc2_level.hpp -- one model level of one grid column of CLOUDSC2: trajectory, tangent-linear
+// and adjoint, as inline device functions.  All three HIP kernels (cloudsc2_kernels.hip) are built from
+// these, so the TL and the AD see bit-identical trajectory values and branch decisions
+// (the reference's linearisation freezes every branch on the trajectory).
+//
+// Design (not a transliteration of the Fortran):
+//   * The reference sweeps (KLON,KLEV) work arrays level by level in ~10 fissioned JL loops
+//     (src/cloudsc2_nl/cloudsc2.F90:339-725).  Here one GPU lane owns one column; a level is a pure
+//     function (inputs at JK, 3 carried scalars) -> (outputs at JK, 3 carried scalars); all
+//     intermediates live in registers (struct LevelTraj).
+//   * The TL (src/cloudsc2_tl/cloudsc2tl.F90:453-1101) recomputes the trajectory statement by statement
+//     next to each perturbation statement; here the level's trajectory is evaluated once into LevelTraj
+//     and level_tl() consumes it.
+//   * The AD (src/cloudsc2_ad/cloudsc2ad.F90) stores 117 (KLON,KLEV) arrays in a forward sweep
+//     (:366-866) and unwinds them (:934-1668).  Here only the 3 carried scalars are checkpointed per
+//     level; the reverse sweep re-evaluates level_forward() for level JK and level_ad() applies the
+//     transposed statements to register-resident adjoints.
+// Operation order inside branch-deciding expressions follows the reference so that branch decisions
+// agree with it to rounding.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+namespace cloudsc2 {
+
+typedef double real_t;
+
+#define C2_HD __host__ __device__ __forceinline__
+
+// Launch-invariant scalars: the module constants plus what CLOUDSC2 derives from them at entry
+// (cloudsc2.F90:235-244, cloudsc2tl.F90:321-332).
+struct Consts {
+  real_t rg, rd, rcpd, retv, rlvtt, rlstt, rlmlt, rtt;
+  real_t r2es, r3les, r3ies, r4les, r4ies, r5les, r5ies, r5alvcp, r5alscp, ralvdcp, ralsdcp;
+  real_t rtwat, rtice, rtwat_rtice_r, rvtmp2;
+  real_t rlmin, rpecons, rlptrc;
+  real_t ptsphy, zckcodtl, zckcodti, zckcodtla, zckcodtia, zcons2, zcons3, zmeltp2, zqtmst;
+  real_t zlcrit_l, zlcrit_i;   // autoconversion thresholds (cloudsc2.F90:505-509,522-526)
+  real_t rcpd_r;               // 1/RCPD
+  real_t zzz0;                 // 1/(RCPD+RCPD*RVTMP2*q) when RVTMP2 == 0
+  int evap;                    // LEVAPLS2 .OR. LDRAIN1D
+  int lregcl;
+  int rvtmp2_zero;
+  int nlev;
+};
+
+// Raw inputs of one level (dummy arguments of CLOUDSC2 at (JL,JK); cloudsc2.F90:124-143).
+struct LevelIn {
+  real_t paph_k, paph_k1;  // PAPHP1(JK), PAPHP1(JK+1)
+  real_t pap, q, qs, t, l, i, lude, lu_k1, mfu, mfd, gt, gq, gl, gi, supsat;  // lu_k1 = PLU(JK+1)
+  real_t paph_surf;        // PAPHP1(KLEV+1), only read when evap
+};
+
+// Carried top->bottom (cloudsc2.F90:305-312,720-723).
+struct Carry {
+  real_t rfl, sfl, covptot;
+};
+
+// Outputs of one level (cloudsc2.F90:709-715,732-733; PCOVPTOT :582).
+struct LevelOut {
+  real_t tent, tenq, tenl, teni, clc, covptot, fplsl, fplsn;  // fluxes at half level JK+1
+};
+
+// Per-level, column-independent values prepared on the host.
+struct LevelCst {
+  real_t ceta, zscalm;  // CETA(JK); ZSCALM(JK) (cloudsc2.F90:266)
+  int last;             // JK == KLEV
+};
+
+// Per-column critical-RH set-up, depends only on ZTRPAUS (cloudsc2.F90:384-390).
+struct RhCrit {
+  real_t zeta3, zrh2, zdeta1;
+};
+
+C2_HD void rhcrit_setup(real_t ztrpaus, RhCrit& r) {
+  r.zeta3 = ztrpaus;
+  real_t d = ztrpaus - 0.25;
+  real_t dq = d / 0.15;
+  r.zrh2 = 0.35 + 0.14 * (dq * dq) + 0.04 * fmin(d, 0.0) / 0.15;
+  r.zdeta1 = 0.09 + 0.16 * (0.4 - ztrpaus) / 0.3;
+}
+
+C2_HD real_t rhcrit_level(const RhCrit& r, real_t ceta) {
+  // cloudsc2.F90:391-399 (ZRH1 = ZRH3 = 1, ZDETA2 = 0.3)
+  const real_t zdeta2 = 0.3;
+  real_t zcrh2 = 1.0;
+  if (ceta < r.zeta3) {
+    zcrh2 = 1.0;
+  } else if (ceta < (r.zeta3 + zdeta2)) {
+    zcrh2 = 1.0 + (r.zrh2 - 1.0) * ((ceta - r.zeta3) / zdeta2);
+  } else if (ceta < (1.0 - r.zdeta1)) {
+    zcrh2 = r.zrh2;
+  } else {
+    zcrh2 = 1.0 + (r.zrh2 - 1.0) * sqrt((1.0 - ceta) / r.zdeta1);
+  }
+  return zcrh2;
+}
+
+// FOEALFA (src/common/include/fcttre.func.h:74-75)
+C2_HD real_t foealfa(const Consts& c, real_t t) {
+  real_t x = (fmax(c.rtice, fmin(c.rtwat, t)) - c.rtice) * c.rtwat_rtice_r;
+  return fmin(1.0, x * x);
+}
+
+// SATUR, LDPHYLIN branch (src/cloudsc2_nl/satur.F90:106-123)
+C2_HD real_t satur_point(const Consts& c, real_t pap, real_t t) {
+  real_t zalfa = foealfa(c, t);
+  real_t zfoeewl = c.r2es * exp(c.r3les * (t - c.rtt) / (t - c.r4les));
+  real_t zfoeewi = c.r2es * exp(c.r3ies * (t - c.rtt) / (t - c.r4ies));
+  real_t zfoeew = zalfa * zfoeewl + (1.0 - zalfa) * zfoeewi;
+  real_t zqs = zfoeew / pap;
+  if (zqs > 0.5) zqs = 0.5;
+  real_t zcor = 1.0 / (1.0 - c.retv * zqs);
+  return zqs * zcor;
+}
+
+// Everything level_tl / level_ad need from the trajectory of one level.  Names follow the "...5" variables of
+// cloudsc2tl.F90 / cloudsc2ad.F90 where one exists.
+struct LevelTraj {
+  // first guess and thermodynamics
+  real_t ztp2, zqp2, zl, zi, zdp, zzz, zlfdcp, zlsdcp, zlvdcp;  // ZTP25, ZQP25
+  // stage A
+  real_t zfwat, zfoeew, zesdp, zfacw, zfaci, zfac, zcor, zdqsdtemp, zcorqs, zqlim, tm4l, tm4i;
+  real_t zcosh2r;  // 1/cosh^2(0.17 (T-RLPTRC))
+  int cold, esdp_clip, qlim_is_qs;
+  // stage B
+  real_t zcrh2, zsupsat, zqsat, zqcrit;
+  int below_rtice;
+  // stage C
+  real_t zqt, zqpd, zqcd, zden, zsqrt, zclc, zqc1;
+  int regime;  // 0 clear, 1 overcast, 2 partial
+  // stage D
+  real_t zgdp, zlude, zexpl, clc, zqc2;  // clc = PCLC5 (final)
+  int llo1;
+  // stage E
+  real_t zfac1, zrho, zfac2, zrodqsdp, zldcp, zfac3, dtdzmo, zdqsdz, zfac4, zdqc, zqc3;
+  int llo3;
+  // stage F
+  real_t zqlwc1, zqiwc1, zcondl1, zcondi1;
+  // stage G
+  real_t covptot_in, covptot1, covpclr1, covpclr;
+  int newmax;
+  // stage H
+  real_t rfl_in, sfl_in, zcons, zz2s, zsnmlt, ztp1;  // ztp1 = ZTP15 (after melting)
+  int melt, warm2, melt_all;
+  // stage I
+  real_t zcldl, zexp3, zdl, zexpdl, zprr, zqlwc, zcldi, zexp1, zexp2, zdi, zexpdi, zprs, zqiwc;
+  real_t zdr1, zrfreeze1, zfwatr1, rfln2, sfln2;
+  int cloudy, frz1;
+  // stage J
+  real_t zprtot, zpreclr1, zqe, zbeta, zb, zdtgdp, zdpr1, zdpr, zpreclr, zevapr, zevaps, omc, zsqp;
+  int llo2, dpr_clip, reset;
+  // stage K
+  real_t ztpb, zqpb;  // ZTPB5, ZQPB5 (= ZQOLD5)
+  // stage L (two adjustment iterations, cuadjtqs.F90:212-244)
+  real_t z3es, z4es, z5alcp, zaldcp, zqp;
+  real_t a_t[2], a_q[2], a_foeew[2], a_qsatu[2], a_cor[2], a_qsat[2], a_z2s[2], a_tm4[2], a_den[2];
+  int a_clip[2];
+  real_t ztp3, zqp1;  // ZTP35, ZQP15 after adjustment
+  // stage M
+  real_t zdq, zdr2, zfwatr2, zcondl2, zcondi2, zrfreeze3;
+  int dq_pos, frz2;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// Trajectory of one level.  cloudsc2.F90:253-279 (first guess) + :343-723.
+// ---------------------------------------------------------------------------------------------------------
+C2_HD void level_forward(const Consts& c, const LevelCst& k, const RhCrit& rh, const LevelIn& x, Carry& cy,
+                         LevelTraj& t, LevelOut& o) {
+  const real_t zqmax = 0.5, zeps2 = 1.e-10;
+
+  // first guess (cloudsc2.F90:255-258) and thermodynamic constants (:272-276)
+  t.ztp2 = x.t + c.ptsphy * x.gt;
+  t.zqp2 = x.q + c.ptsphy * x.gq + x.supsat;
+  t.zl = x.l + c.ptsphy * x.gl;
+  t.zi = x.i + c.ptsphy * x.gi;
+  t.zdp = x.paph_k1 - x.paph_k;
+  t.zzz = c.rvtmp2_zero ? c.zzz0 : 1.0 / (c.rcpd + c.rcpd * c.rvtmp2 * t.zqp2);
+  t.zlfdcp = c.rlmlt * t.zzz;
+  t.zlsdcp = c.rlstt * t.zzz;
+  t.zlvdcp = c.rlvtt * t.zzz;
+
+  // A. mixed phase and dqs/dT (cloudsc2.F90:350-375, LPHYLIN branch)
+  {
+    real_t u = 0.17 * (t.ztp2 - c.rlptrc);
+    real_t th = tanh(u);
+    real_t ch = cosh(u);                               // only live in the TL/AD kernels
+    t.zcosh2r = 1.0 / (ch * ch);
+    real_t zoealfaw = 0.545 * (th + 1.0);
+    t.cold = t.ztp2 < c.rtt;
+    real_t z3es, z4es;
+    if (t.cold) { t.zfwat = zoealfaw; z3es = c.r3ies; z4es = c.r4ies; }
+    else        { t.zfwat = 1.0;      z3es = c.r3les; z4es = c.r4les; }
+    t.zfoeew = c.r2es * exp(z3es * (t.ztp2 - c.rtt) / (t.ztp2 - z4es));
+    real_t zesdp1 = t.zfoeew / x.pap;
+    t.esdp_clip = zesdp1 > zqmax;
+    t.zesdp = t.esdp_clip ? zqmax : zesdp1;
+    t.tm4l = t.ztp2 - c.r4les;
+    t.tm4i = t.ztp2 - c.r4ies;
+    t.zfacw = c.r5les / (t.tm4l * t.tm4l);
+    t.zfaci = c.r5ies / (t.tm4i * t.tm4i);
+    t.zfac = t.zfwat * t.zfacw + (1.0 - t.zfwat) * t.zfaci;
+    t.zcor = 1.0 / (1.0 - c.retv * t.zesdp);
+    t.zdqsdtemp = t.zfac * t.zcor * x.qs;
+    t.zcorqs = 1.0 + c.zcons3 * t.zdqsdtemp;
+    t.qlim_is_qs = t.zqp2 > x.qs;
+    t.zqlim = t.qlim_is_qs ? x.qs : t.zqp2;
+  }
+
+  // B. critical relative humidity (cloudsc2.F90:384-407)
+  t.zcrh2 = rhcrit_level(rh, k.ceta);
+  t.below_rtice = t.ztp2 < c.rtice;
+  t.zsupsat = t.below_rtice ? (1.8 - 3.e-03 * t.ztp2) : 1.0;
+  t.zqsat = x.qs * t.zsupsat;
+  t.zqcrit = t.zcrh2 * t.zqsat;
+
+  // C. uniform-PDF cloud cover (cloudsc2.F90:413-426)
+  t.zqt = t.zqp2 + t.zl + t.zi;
+  t.zqpd = 0.0; t.zqcd = 0.0; t.zden = 1.0; t.zsqrt = 1.0;
+  if (t.zqt <= t.zqcrit) {
+    t.regime = 0; t.zclc = 0.0; t.zqc1 = 0.0;
+  } else if (t.zqt >= t.zqsat) {
+    t.regime = 1; t.zclc = 1.0; t.zqc1 = (1.0 - k.zscalm) * (t.zqsat - t.zqcrit);
+  } else {
+    t.regime = 2;
+    t.zqpd = t.zqsat - t.zqt;
+    t.zqcd = t.zqsat - t.zqcrit;
+    t.zden = t.zqcd - k.zscalm * (t.zqt - t.zqcrit);
+    t.zsqrt = sqrt(t.zqpd / t.zden);
+    t.zclc = 1.0 - t.zsqrt;
+    t.zqc1 = (k.zscalm * t.zqpd + (1.0 - k.zscalm) * t.zqcd) * (t.zclc * t.zclc);
+  }
+
+  // D. convective component (cloudsc2.F90:432-443)
+  t.zgdp = c.rg / (x.paph_k1 - x.paph_k);
+  t.zlude = x.lude * c.ptsphy * t.zgdp;
+  t.llo1 = (!k.last) && (t.zlude >= c.rlmin) && (x.lu_k1 >= zeps2);
+  t.zexpl = 1.0;
+  if (t.llo1) {
+    t.zexpl = exp(-t.zlude / x.lu_k1);
+    t.clc = t.zclc + (1.0 - t.zclc) * (1.0 - t.zexpl);
+    t.zqc2 = t.zqc1 + t.zlude;
+  } else {
+    t.clc = t.zclc;
+    t.zqc2 = t.zqc1;
+  }
+
+  // E. compensating subsidence (cloudsc2.F90:449-459)
+  t.zfac1 = 1.0 / (c.rd * t.ztp2);
+  t.zrho = x.pap * t.zfac1;
+  t.zfac2 = 1.0 / (x.pap - c.retv * t.zfoeew);
+  t.zrodqsdp = -t.zrho * x.qs * t.zfac2;
+  t.zldcp = t.zfwat * t.zlvdcp + (1.0 - t.zfwat) * t.zlsdcp;
+  t.zfac3 = 1.0 / (1.0 + t.zldcp * t.zdqsdtemp);
+  t.dtdzmo = c.rg * (c.rcpd_r - t.zldcp * t.zrodqsdp) * t.zfac3;
+  t.zdqsdz = t.zdqsdtemp * t.dtdzmo - c.rg * t.zrodqsdp;
+  t.zfac4 = 1.0 / t.zrho;
+  {
+    real_t xdq = t.zdqsdz * (x.mfu + x.mfd) * c.ptsphy * t.zfac4;
+    t.llo3 = xdq < t.zqc2;
+    t.zdqc = t.llo3 ? xdq : t.zqc2;
+  }
+  t.zqc3 = t.zqc2 - t.zdqc;
+
+  // F. condensate partition and condensation rates (cloudsc2.F90:465-468)
+  t.zqlwc1 = t.zqc3 * t.zfwat;
+  t.zqiwc1 = t.zqc3 * (1.0 - t.zfwat);
+  t.zcondl1 = (t.zqlwc1 - t.zl) * c.zqtmst;
+  t.zcondi1 = (t.zqiwc1 - t.zi) * c.zqtmst;
+
+  // G. maximum overlap of precipitation (cloudsc2.F90:476-480)
+  t.covptot_in = cy.covptot;
+  t.newmax = t.clc > cy.covptot;
+  t.covptot1 = t.newmax ? t.clc : cy.covptot;
+  t.covpclr1 = t.covptot1 - t.clc;
+  t.covpclr = (t.covpclr1 < 0.0) ? 0.0 : t.covpclr1;
+
+  // H. melting of incoming snow (cloudsc2.F90:488-497)
+  t.rfl_in = cy.rfl;
+  t.sfl_in = cy.sfl;
+  t.melt = cy.sfl != 0.0;
+  real_t rfln, sfln;
+  t.zcons = 1.0; t.zz2s = 0.0; t.zsnmlt = 0.0; t.warm2 = 0; t.melt_all = 0;
+  if (t.melt) {
+    t.zcons = c.zcons2 * t.zdp / t.zlfdcp;
+    t.warm2 = (t.ztp2 - c.zmeltp2) > 0.0;
+    t.zz2s = t.warm2 ? t.zcons * (t.ztp2 - c.zmeltp2) : 0.0;
+    t.melt_all = cy.sfl <= t.zz2s;
+    t.zsnmlt = t.melt_all ? cy.sfl : t.zz2s;
+    rfln = cy.rfl + t.zsnmlt;
+    sfln = cy.sfl - t.zsnmlt;
+    t.ztp1 = t.ztp2 - t.zsnmlt / t.zcons;
+  } else {
+    rfln = cy.rfl;
+    sfln = cy.sfl;
+    t.ztp1 = t.ztp2;
+  }
+
+  // I. autoconversion to rain and snow (cloudsc2.F90:504-552)
+  t.cloudy = t.clc > zeps2;
+  if (t.cloudy) {
+    t.zcldl = t.zqlwc1 / t.clc;
+    real_t ql = t.zcldl / c.zlcrit_l;
+    t.zexp3 = exp(-(ql * ql));
+    t.zdl = c.zckcodtl * (1.0 - t.zexp3);
+    t.zexpdl = exp(-t.zdl);
+    real_t zlnew = t.clc * t.zcldl * t.zexpdl;
+    t.zprr = t.zqlwc1 - zlnew;
+    t.zqlwc = t.zqlwc1 - t.zprr;
+
+    t.zcldi = t.zqiwc1 / t.clc;
+    real_t qi = t.zcldi / c.zlcrit_i;
+    t.zexp1 = exp(0.025 * (t.ztp1 - c.rtt));
+    t.zexp2 = exp(-(qi * qi));
+    t.zdi = c.zckcodti * t.zexp1 * (1.0 - t.zexp2);
+    t.zexpdi = exp(-t.zdi);
+    real_t zinew = t.clc * t.zcldi * t.zexpdi;
+    t.zprs = t.zqiwc1 - zinew;
+    t.zqiwc = t.zqiwc1 - t.zprs;
+  } else {
+    t.zcldl = 0.0; t.zexp3 = 1.0; t.zdl = 0.0; t.zexpdl = 1.0; t.zprr = 0.0; t.zqlwc = t.zqlwc1;
+    t.zcldi = 0.0; t.zexp1 = 1.0; t.zexp2 = 1.0; t.zdi = 0.0; t.zexpdi = 1.0; t.zprs = 0.0; t.zqiwc = t.zqiwc1;
+  }
+  t.zdr1 = c.zcons2 * t.zdp * (t.zprr + t.zprs);
+  t.frz1 = t.ztp1 < c.rtt;
+  if (t.frz1) { t.zrfreeze1 = c.zcons2 * t.zdp * t.zprr; t.zfwatr1 = 0.0; }
+  else        { t.zrfreeze1 = 0.0;                        t.zfwatr1 = 1.0; }
+  rfln = rfln + t.zfwatr1 * t.zdr1;
+  sfln = sfln + (1.0 - t.zfwatr1) * t.zdr1;
+  t.rfln2 = rfln;
+  t.sfln2 = sfln;
+
+  // J. evaporation of precipitation (cloudsc2.F90:556-591); dead unless LEVAPLS2 .OR. LDRAIN1D
+  t.zprtot = rfln + sfln;
+  t.llo2 = c.evap && (t.zprtot > zeps2) && (t.covpclr > zeps2);
+  real_t covptot = t.covptot1;
+  real_t pcovptot = 0.0;
+  t.zevapr = 0.0; t.zevaps = 0.0;
+  t.dpr_clip = 0; t.reset = 0;
+  t.zpreclr1 = 0.0; t.zqe = 0.0; t.zbeta = 0.0; t.zb = 0.0; t.zdtgdp = 1.0; t.zdpr1 = 0.0; t.zdpr = 0.0;
+  t.zpreclr = 0.0; t.omc = 1.0; t.zsqp = 1.0;
+  if (t.llo2) {
+    t.zpreclr1 = t.zprtot * t.covpclr / t.covptot1;
+    t.omc = 1.0 - t.clc;
+    t.zqe = x.qs - (x.qs - t.zqlim) * t.covpclr / (t.omc * t.omc);
+    t.zsqp = sqrt(x.pap / x.paph_surf);
+    t.zbeta = c.rg * c.rpecons * pow(t.zsqp / 5.09e-3 * t.zpreclr1 / t.covpclr, 0.5777);
+    t.zb = c.ptsphy * t.zbeta * (x.qs - t.zqe) / (1.0 + t.zbeta * c.ptsphy * t.zcorqs);
+    t.zdtgdp = c.ptsphy * c.rg / (x.paph_k1 - x.paph_k);
+    t.zdpr1 = t.covpclr * t.zb / t.zdtgdp;
+    t.dpr_clip = t.zdpr1 > t.zpreclr1;
+    t.zdpr = t.dpr_clip ? t.zpreclr1 : t.zdpr1;
+    t.zpreclr = t.zpreclr1 - t.zdpr;
+    t.reset = t.zpreclr <= 0.0;
+    if (t.reset) covptot = t.clc;
+    pcovptot = covptot;
+    t.zevapr = t.zdpr * t.rfln2 / t.zprtot;
+    rfln = rfln - t.zevapr;
+    t.zevaps = t.zdpr * t.sfln2 / t.zprtot;
+    sfln = sfln - t.zevaps;
+  }
+
+  // K. first-guess T and q after the cloud processes (cloudsc2.F90:602-617)
+  {
+    real_t zdqdt = -(t.zcondl1 + t.zcondi1) + (x.lude + t.zevapr + t.zevaps) * t.zgdp;
+    real_t zdtdt = t.zlvdcp * t.zcondl1 + t.zlsdcp * t.zcondi1 -
+                   (t.zlvdcp * t.zevapr + t.zlsdcp * t.zevaps +
+                    x.lude * (t.zfwat * t.zlvdcp + (1.0 - t.zfwat) * t.zlsdcp) -
+                    (t.zlsdcp - t.zlvdcp) * t.zrfreeze1) * t.zgdp;
+    t.ztpb = t.ztp1 + c.ptsphy * zdtdt;
+    t.zqpb = t.zqp2 + c.ptsphy * zdqdt;
+  }
+
+  // L. saturation adjustment, two iterations (cloudsc2.F90:630-669 == cuadjtqs.F90:212-244)
+  {
+    if (t.ztpb > c.rtt) { t.z3es = c.r3les; t.z4es = c.r4les; t.z5alcp = c.r5alvcp; t.zaldcp = c.ralvdcp; }
+    else                { t.z3es = c.r3ies; t.z4es = c.r4ies; t.z5alcp = c.r5alscp; t.zaldcp = c.ralsdcp; }
+    t.zqp = 1.0 / x.pap;
+    real_t tt = t.ztpb, qq = t.zqpb;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      t.a_t[it] = tt;
+      t.a_q[it] = qq;
+      t.a_tm4[it] = tt - t.z4es;
+      t.a_foeew[it] = c.r2es * exp(t.z3es * (tt - c.rtt) / t.a_tm4[it]);
+      real_t qs1 = t.zqp * t.a_foeew[it];
+      t.a_clip[it] = qs1 > zqmax;
+      if (t.a_clip[it]) qs1 = zqmax;
+      t.a_qsatu[it] = qs1;
+      t.a_cor[it] = 1.0 / (1.0 - c.retv * qs1);
+      t.a_qsat[it] = qs1 * t.a_cor[it];
+      t.a_z2s[it] = t.z5alcp / (t.a_tm4[it] * t.a_tm4[it]);
+      t.a_den[it] = 1.0 + t.a_qsat[it] * t.a_cor[it] * t.a_z2s[it];
+      real_t zcond1 = (qq - t.a_qsat[it]) / t.a_den[it];
+      tt = tt + t.zaldcp * zcond1;
+      qq = qq - zcond1;
+    }
+    t.ztp3 = tt;
+    t.zqp1 = qq;
+  }
+
+  // M. extra condensation goes to precipitation; final tendencies (cloudsc2.F90:673-716)
+  {
+    real_t d = t.zqpb - t.zqp1;
+    t.dq_pos = d >= 0.0;
+    t.zdq = t.dq_pos ? d : 0.0;
+    t.zdr2 = c.zcons2 * t.zdp * t.zdq;
+    t.frz2 = t.ztp3 < c.rtt;
+    real_t zrfreeze2;
+    if (t.frz2) { zrfreeze2 = t.zfwat * t.zdr2; t.zfwatr2 = 0.0; }
+    else        { zrfreeze2 = 0.0;              t.zfwatr2 = 1.0; }
+    t.zcondl2 = t.zcondl1 + t.zfwatr2 * t.zdq * c.zqtmst;
+    t.zcondi2 = t.zcondi1 + (1.0 - t.zfwatr2) * t.zdq * c.zqtmst;
+    rfln = rfln + t.zfwatr2 * t.zdr2;
+    sfln = sfln + (1.0 - t.zfwatr2) * t.zdr2;
+    t.zrfreeze3 = t.zrfreeze1 + zrfreeze2;
+
+    o.tenq = -(t.zcondl2 + t.zcondi2) + (x.lude + t.zevapr + t.zevaps) * t.zgdp;
+    o.tent = t.zlvdcp * t.zcondl2 + t.zlsdcp * t.zcondi2 -
+             (t.zlvdcp * t.zevapr + t.zlsdcp * t.zevaps +
+              x.lude * (t.zfwat * t.zlvdcp + (1.0 - t.zfwat) * t.zlsdcp) -
+              (t.zlsdcp - t.zlvdcp) * t.zrfreeze3) * t.zgdp;
+    o.tenl = (t.zqlwc - t.zl) * c.zqtmst;
+    o.teni = (t.zqiwc - t.zi) * c.zqtmst;
+    o.clc = t.clc;
+    o.covptot = pcovptot;
+    o.fplsl = rfln;
+    o.fplsn = sfln;
+  }
+
+  // N. carry (cloudsc2.F90:720-723)
+  cy.rfl = rfln;
+  cy.sfl = sfln;
+  cy.covptot = covptot;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Tangent-linear of one level about LevelTraj.  cloudsc2tl.F90:343-373 (first guess) + :457-1099,
+// CUADJTQSTL KCALL=0 (cuadjtqstl.F90:333-405).  dx = perturbation inputs, dcy = perturbation carries.
+// ---------------------------------------------------------------------------------------------------------
+C2_HD void level_tl(const Consts& c, const LevelCst& k, const LevelIn& x, const LevelTraj& t, const LevelIn& dx,
+                    Carry& dcy, LevelOut& dout) {
+  // first guess
+  real_t ztp1 = dx.t + c.ptsphy * dx.gt;
+  real_t zqp1 = dx.q + c.ptsphy * dx.gq + dx.supsat;
+  real_t zl = dx.l + c.ptsphy * dx.gl;
+  real_t zi = dx.i + c.ptsphy * dx.gi;
+  real_t zdp = dx.paph_k1 - dx.paph_k;
+  real_t zzz = c.rvtmp2_zero ? 0.0 : -c.rcpd * c.rvtmp2 * zqp1 * (t.zzz * t.zzz);
+  real_t zlfdcp = c.rlmlt * zzz, zlsdcp = c.rlstt * zzz, zlvdcp = c.rlvtt * zzz;
+
+  // A (cloudsc2tl.F90:463-501)
+  real_t zfwat, z3es, z4es, tm4;
+  if (t.cold) { zfwat = 0.545 * 0.17 * ztp1 * t.zcosh2r; z3es = c.r3ies; z4es = c.r4ies; tm4 = t.tm4i; }
+  else        { zfwat = 0.0;                            z3es = c.r3les; z4es = c.r4les; tm4 = t.tm4l; }
+  real_t zfoeew = z3es * (c.rtt - z4es) * ztp1 * t.zfoeew / (tm4 * tm4);
+  real_t zesdp = zfoeew / x.pap - dx.pap * t.zfoeew / (x.pap * x.pap);
+  if (t.esdp_clip) zesdp = 0.0;
+  real_t zfacw = -2.0 * c.r5les * ztp1 / (t.tm4l * t.tm4l * t.tm4l);
+  real_t zfaci = -2.0 * c.r5ies * ztp1 / (t.tm4i * t.tm4i * t.tm4i);
+  real_t zfac = t.zfwat * zfacw + t.zfacw * zfwat + (1.0 - t.zfwat) * zfaci - t.zfaci * zfwat;
+  real_t zcor = c.retv * zesdp * (t.zcor * t.zcor);
+  real_t zdqsdtemp = t.zfac * t.zcor * dx.qs + t.zfac * x.qs * zcor + t.zcor * x.qs * zfac;
+  real_t zcorqs = c.zcons3 * zdqsdtemp;
+  real_t zqlim = t.qlim_is_qs ? dx.qs : zqp1;
+
+  // B (cloudsc2tl.F90:532-543)
+  real_t zsupsat = t.below_rtice ? (-3.e-03 * ztp1) : 0.0;
+  real_t zqsat = dx.qs * t.zsupsat + x.qs * zsupsat;
+  real_t zqcrit = t.zcrh2 * zqsat;
+
+  // C (cloudsc2tl.F90:549-589)
+  real_t zqt = zqp1 + zl + zi;
+  real_t pclc, zqc;
+  if (t.regime == 0) {
+    pclc = 0.0; zqc = 0.0;
+  } else if (t.regime == 1) {
+    pclc = 0.0; zqc = (1.0 - k.zscalm) * (zqsat - zqcrit);
+  } else {
+    real_t zqpd = zqsat - zqt;
+    real_t zqcd = zqsat - zqcrit;
+    pclc = -(0.5 / t.zsqrt) * (zqpd * t.zden - t.zqpd * (zqcd - k.zscalm * (zqt - zqcrit))) / (t.zden * t.zden);
+    if (c.lregcl) {
+      real_t zrat = t.zqpd / t.zqcd;
+      real_t w = 1.0 - k.zscalm * (1.0 - zrat);
+      real_t zyyy = fmin(0.3, 3.5 * sqrt(zrat * (w * w * w)) / (1.0 - k.zscalm));
+      pclc = zyyy * pclc;
+    }
+    zqc = (k.zscalm * zqpd + (1.0 - k.zscalm) * zqcd) * (t.zclc * t.zclc) +
+          (k.zscalm * t.zqpd + (1.0 - k.zscalm) * t.zqcd) * 2.0 * t.zclc * pclc;
+  }
+
+  // D (cloudsc2tl.F90:595-622)
+  real_t dpk = x.paph_k1 - x.paph_k;
+  real_t zgdp = -c.rg * (dx.paph_k1 - dx.paph_k) / (dpk * dpk);
+  real_t zlude = c.ptsphy * t.zgdp * dx.lude + c.ptsphy * x.lude * zgdp;
+  if (t.llo1) {
+    pclc = pclc - pclc * (1.0 - t.zexpl) + ((1.0 - t.zclc) / x.lu_k1) * t.zexpl * zlude -
+           ((1.0 - t.zclc) * t.zlude / (x.lu_k1 * x.lu_k1)) * t.zexpl * dx.lu_k1;
+    zqc = zqc + zlude;
+  }
+
+  // E (cloudsc2tl.F90:628-664)
+  {
+    real_t zrho = (dx.pap - ztp1 * x.pap / t.ztp2) * t.zfac1;
+    real_t zrodqsdp = (-zrho * x.qs - t.zrho * dx.qs + t.zrho * x.qs * (dx.pap - c.retv * zfoeew) * t.zfac2) * t.zfac2;
+    real_t zldcp = zfwat * t.zlvdcp + t.zfwat * zlvdcp + (1.0 - t.zfwat) * zlsdcp - zfwat * t.zlsdcp;
+    real_t dtdzmo = -(c.rg * (zldcp * t.zrodqsdp + t.zldcp * zrodqsdp) +
+                      t.dtdzmo * (t.zldcp * zdqsdtemp + zldcp * t.zdqsdtemp)) * t.zfac3;
+    real_t zdqsdz = t.zdqsdtemp * dtdzmo + zdqsdtemp * t.dtdzmo - c.rg * zrodqsdp;
+    real_t zdqc;
+    if (t.llo3) {
+      zdqc = (c.ptsphy * (zdqsdz * (x.mfu + x.mfd) + t.zdqsdz * (dx.mfu + dx.mfd)) - t.zdqc * zrho) * t.zfac4;
+      if (c.lregcl) zdqc = zdqc * 0.1;
+    } else {
+      zdqc = zqc;
+    }
+    zqc = zqc - zdqc;
+  }
+
+  // F (cloudsc2tl.F90:670-680)
+  real_t zqlwc = zqc * t.zfwat + t.zqc3 * zfwat;
+  real_t zqiwc = zqc * (1.0 - t.zfwat) - t.zqc3 * zfwat;
+  real_t zcondl = (zqlwc - zl) * c.zqtmst;
+  real_t zcondi = (zqiwc - zi) * c.zqtmst;
+
+  // G (cloudsc2tl.F90:687-696)
+  real_t zcovptot = t.newmax ? pclc : dcy.covptot;
+  real_t zcovpclr = zcovptot - pclc;
+  if (t.covpclr1 < 0.0) zcovpclr = 0.0;
+
+  // H (cloudsc2tl.F90:704-733)
+  real_t zrfln, zsfln;
+  if (t.melt) {
+    real_t zcons = c.zcons2 * (zdp * t.zlfdcp - t.zdp * zlfdcp) / (t.zlfdcp * t.zlfdcp);
+    real_t zz2s = t.warm2 ? (t.zcons * ztp1 + zcons * (t.ztp2 - c.zmeltp2)) : 0.0;
+    real_t zsnmlt = t.melt_all ? dcy.sfl : zz2s;
+    zrfln = dcy.rfl + zsnmlt;
+    zsfln = dcy.sfl - zsnmlt;
+    ztp1 = ztp1 - (zsnmlt * t.zcons - zcons * t.zsnmlt) / (t.zcons * t.zcons);
+  } else {
+    zrfln = dcy.rfl;
+    zsfln = dcy.sfl;
+  }
+
+  // I (cloudsc2tl.F90:739-840)
+  real_t zprr = 0.0, zprs = 0.0;
+  if (t.cloudy) {
+    real_t zcldl = zqlwc / t.clc - t.zqlwc1 * pclc / (t.clc * t.clc);
+    real_t ck = c.lregcl ? c.zckcodtla : c.zckcodtl;
+    real_t zd = (2.0 * ck / (c.zlcrit_l * c.zlcrit_l)) * t.zexp3 * t.zcldl * zcldl;
+    real_t zlnew = t.zcldl * t.zexpdl * pclc + t.clc * t.zexpdl * zcldl - t.clc * t.zcldl * t.zexpdl * zd;
+    zprr = zqlwc - zlnew;
+    zqlwc = zqlwc - zprr;
+
+    real_t zcldi = zqiwc / t.clc - t.zqiwc1 * pclc / (t.clc * t.clc);
+    real_t cki = c.lregcl ? c.zckcodtia : c.zckcodti;
+    real_t zdi = cki * t.zexp1 *
+                 (t.zexp2 * (2.0 * t.zcldi * zcldi / (c.zlcrit_i * c.zlcrit_i) - 0.025 * ztp1) + 0.025 * ztp1);
+    real_t zinew = t.zcldi * t.zexpdi * pclc + t.clc * t.zexpdi * zcldi - t.clc * t.zcldi * t.zexpdi * zdi;
+    zprs = zqiwc - zinew;
+    zqiwc = zqiwc - zprs;
+  }
+  real_t zdr = c.zcons2 * (t.zdp * (zprr + zprs) + zdp * (t.zprr + t.zprs));
+  real_t zrfreeze = 0.0;
+  if (t.frz1) zrfreeze = c.zcons2 * (zdp * t.zprr + t.zdp * zprr);
+  zrfln = zrfln + t.zfwatr1 * zdr;
+  zsfln = zsfln + (1.0 - t.zfwatr1) * zdr;
+
+  // J (cloudsc2tl.F90:844-936)
+  real_t zevapr = 0.0, zevaps = 0.0, pcovptot = 0.0;
+  if (t.llo2) {
+    real_t zprtot = zrfln + zsfln;
+    real_t zpreclr = (t.zprtot * zcovpclr + t.covpclr * zprtot) / t.covptot1 -
+                     t.zprtot * t.covpclr * zcovptot / (t.covptot1 * t.covptot1);
+    real_t omc2 = t.omc * t.omc;
+    real_t zqe = dx.qs - ((x.qs - t.zqlim) * zcovpclr + t.covpclr * dx.qs - t.covpclr * zqlim) / omc2 -
+                 2.0 * (x.qs - t.zqlim) * t.covpclr * pclc / (omc2 * t.omc);
+    real_t zbeta = 0.5777 * (c.rg * c.rpecons / 5.09e-3) *
+                   pow(5.09e-3 * t.covpclr / (t.zpreclr1 * t.zsqp), 0.4223) *
+                   ((t.zsqp * zpreclr + 0.5 * t.zpreclr1 * dx.pap / sqrt(x.pap * x.paph_surf) -
+                     0.5 * t.zpreclr1 * t.zsqp * dx.paph_surf / x.paph_surf) / t.covpclr -
+                    t.zpreclr1 * t.zsqp * zcovpclr / (t.covpclr * t.covpclr));
+    real_t den = 1.0 + t.zbeta * c.ptsphy * t.zcorqs;
+    real_t zb = c.ptsphy * ((x.qs - t.zqe) * zbeta + t.zbeta * dx.qs - t.zbeta * zqe) / den -
+                (c.ptsphy * c.ptsphy) * t.zbeta * (x.qs - t.zqe) * (t.zbeta * zcorqs + t.zcorqs * zbeta) / (den * den);
+    real_t zdtgdp = -c.ptsphy * c.rg * (dx.paph_k1 - dx.paph_k) / (dpk * dpk);
+    real_t zdpr = (t.covpclr * zb + t.zb * zcovpclr) / t.zdtgdp - t.covpclr * t.zb * zdtgdp / (t.zdtgdp * t.zdtgdp);
+    if (t.dpr_clip) zdpr = zpreclr;
+    zpreclr = zpreclr - zdpr;
+    if (t.reset) zcovptot = pclc;
+    pcovptot = zcovptot;
+    zevapr = (t.zdpr * zrfln + t.rfln2 * zdpr) / t.zprtot - t.zdpr * t.rfln2 * zprtot / (t.zprtot * t.zprtot);
+    zevaps = (t.zdpr * zsfln + t.sfln2 * zdpr) / t.zprtot - t.zdpr * t.sfln2 * zprtot / (t.zprtot * t.zprtot);
+    zrfln = zrfln - zevapr;
+    zsfln = zsfln - zevaps;
+  }
+
+  // K (cloudsc2tl.F90:943-982)
+  real_t w5 = t.zfwat * t.zlvdcp + (1.0 - t.zfwat) * t.zlsdcp;
+  real_t w = zfwat * (t.zlvdcp - t.zlsdcp) + (t.zfwat * zlvdcp + (1.0 - t.zfwat) * zlsdcp);
+  {
+    real_t zdqdt = -(zcondl + zcondi) + (dx.lude + zevapr + zevaps) * t.zgdp + (x.lude + t.zevapr + t.zevaps) * zgdp;
+    real_t zdtdt = zlvdcp * t.zcondl1 + zlsdcp * t.zcondi1 + t.zlvdcp * zcondl + t.zlsdcp * zcondi -
+                   (zlvdcp * t.zevapr + zlsdcp * t.zevaps + t.zlvdcp * zevapr + t.zlsdcp * zevaps +
+                    dx.lude * w5 + x.lude * w - (zlsdcp - zlvdcp) * t.zrfreeze1 -
+                    (t.zlsdcp - t.zlvdcp) * zrfreeze) * t.zgdp -
+                   (t.zlvdcp * t.zevapr + t.zlsdcp * t.zevaps + x.lude * w5 -
+                    (t.zlsdcp - t.zlvdcp) * t.zrfreeze1) * zgdp;
+    ztp1 = ztp1 + c.ptsphy * zdtdt;
+    zqp1 = zqp1 + c.ptsphy * zdqdt;
+  }
+  real_t zqold = zqp1;
+
+  // L (cuadjtqstl.F90:339-402)
+  {
+    real_t zqp = -dx.pap * (t.zqp * t.zqp);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      real_t tm4a = t.a_tm4[it];
+      real_t dfoeew = t.z3es * (c.rtt - t.z4es) * ztp1 * t.a_foeew[it] / (tm4a * tm4a);
+      real_t dqsat = t.zqp * dfoeew + zqp * t.a_foeew[it];
+      if (t.a_clip[it]) dqsat = 0.0;
+      real_t dcor = (c.retv * dqsat) * (t.a_cor[it] * t.a_cor[it]);
+      dqsat = t.a_qsatu[it] * dcor + dqsat * t.a_cor[it];
+      real_t dz2s = -2.0 * ztp1 * t.z5alcp / (tm4a * tm4a * tm4a);
+      real_t den = t.a_den[it];
+      real_t dcond = (zqp1 - dqsat) / den -
+                     (t.a_q[it] - t.a_qsat[it]) *
+                         (dqsat * t.a_cor[it] * t.a_z2s[it] + t.a_qsat[it] * dcor * t.a_z2s[it] +
+                          t.a_qsat[it] * t.a_cor[it] * dz2s) / (den * den);
+      ztp1 = ztp1 + t.zaldcp * dcond;
+      zqp1 = zqp1 - dcond;
+    }
+  }
+
+  // M (cloudsc2tl.F90:994-1091)
+  {
+    real_t zdq = 0.0;
+    if (t.dq_pos) {
+      zdq = zqold - zqp1;
+      if (c.lregcl) zdq = zdq * 0.7;
+    }
+    real_t zdr2 = c.zcons2 * (t.zdp * zdq + t.zdq * zdp);
+    real_t zrfreeze2 = 0.0;
+    if (t.frz2) zrfreeze2 = zfwat * t.zdr2 + t.zfwat * zdr2;
+    zcondl = zcondl + (t.zfwatr2 * zdq) * c.zqtmst;
+    zcondi = zcondi + ((1.0 - t.zfwatr2) * zdq) * c.zqtmst;
+    zrfln = zrfln + t.zfwatr2 * zdr2;
+    zsfln = zsfln + (1.0 - t.zfwatr2) * zdr2;
+    zrfreeze = zrfreeze + zrfreeze2;
+
+    dout.tenq = -(zcondl + zcondi) + (dx.lude + zevapr + zevaps) * t.zgdp + (x.lude + t.zevapr + t.zevaps) * zgdp;
+    dout.tent = zlvdcp * t.zcondl2 + zlsdcp * t.zcondi2 + t.zlvdcp * zcondl + t.zlsdcp * zcondi -
+                (zlvdcp * t.zevapr + zlsdcp * t.zevaps + t.zlvdcp * zevapr + t.zlsdcp * zevaps +
+                 dx.lude * w5 + x.lude * w - (zlsdcp - zlvdcp) * t.zrfreeze3 -
+                 (t.zlsdcp - t.zlvdcp) * zrfreeze) * t.zgdp -
+                (t.zlvdcp * t.zevapr + t.zlsdcp * t.zevaps + x.lude * w5 -
+                 (t.zlsdcp - t.zlvdcp) * t.zrfreeze3) * zgdp;
+    dout.tenl = (zqlwc - zl) * c.zqtmst;
+    dout.teni = (zqiwc - zi) * c.zqtmst;
+    dout.clc = pclc;
+    dout.covptot = pcovptot;
+    dout.fplsl = zrfln;
+    dout.fplsn = zsfln;
+  }
+
+  dcy.rfl = zrfln;
+  dcy.sfl = zsfln;
+  dcy.covptot = zcovptot;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Adjoint of one level.  cloudsc2ad.F90:940-1666 + the per-level parts of its epilogue (:1701-1738),
+// CUADJTQSAD KCALL=0 (cuadjtqsad.F90:542-641).
+//   ya   : output adjoints of this level (tent,tenq,tenl,teni,clc,covptot and fplsl/fplsn at JK+1 with the
+//          enthalpy-flux adjoints already folded in, cloudsc2ad.F90:914-921)
+//   acy  : adjoint carries.  In: adjoints of (rfl,sfl,covptot) leaving this level downward.
+//          Out: adjoints of the values entering this level from above.
+//   ax   : adjoint increments of the level's inputs (to be added to the input-adjoint arrays);
+//          ax.paph_k / ax.paph_k1 / ax.lu_k1 / ax.paph_surf are contributions to neighbouring indices.
+// ---------------------------------------------------------------------------------------------------------
+C2_HD void level_ad(const Consts& c, const LevelCst& k, const LevelIn& x, const LevelTraj& t, const LevelOut& ya,
+                    Carry& acy, LevelIn& ax) {
+  // adjoints of level-local quantities
+  real_t a_tp1 = 0.0, a_qp1 = 0.0, a_l = 0.0, a_i = 0.0, a_dp = 0.0;
+  real_t a_lvdcp = 0.0, a_lsdcp = 0.0, a_lfdcp = 0.0;
+  real_t a_qlwc = 0.0, a_qiwc = 0.0, a_condl = 0.0, a_condi = 0.0, a_evapr = 0.0, a_evaps = 0.0;
+  real_t a_rfreeze = 0.0, a_gdp = 0.0, a_fwat = 0.0, a_clc = ya.clc, a_lude_in = 0.0;
+  real_t a_pap = 0.0, a_qs = 0.0, a_mfu = 0.0, a_mfd = 0.0, a_lu_k1 = 0.0, a_paph_k = 0.0, a_paph_k1 = 0.0;
+  real_t a_paph_surf = 0.0;
+  real_t a_covptot = acy.covptot, a_covpclr = 0.0, a_qlim = 0.0, a_corqs = 0.0, a_dqsdtemp = 0.0;
+
+  const real_t w5 = t.zfwat * t.zlvdcp + (1.0 - t.zfwat) * t.zlsdcp;
+
+  // fluxes leaving the level (cloudsc2ad.F90:941-957)
+  real_t a_sfln = acy.sfl + ya.fplsn;
+  real_t a_rfln = acy.rfl + ya.fplsl;
+
+  // M^T: final tendencies (cloudsc2ad.F90:959-1012)
+  {
+    real_t zdidt = ya.teni, zdldt = ya.tenl, zdtdt = ya.tent, zdqdt = ya.tenq;
+    a_i -= c.zqtmst * zdidt;  a_qiwc += c.zqtmst * zdidt;
+    a_l -= c.zqtmst * zdldt;  a_qlwc += c.zqtmst * zdldt;
+    a_gdp -= zdtdt * (t.zlvdcp * t.zevapr + t.zlsdcp * t.zevaps + x.lude * w5 - (t.zlsdcp - t.zlvdcp) * t.zrfreeze3);
+    a_condl += zdtdt * t.zlvdcp;
+    a_condi += zdtdt * t.zlsdcp;
+    a_evapr -= zdtdt * t.zlvdcp * t.zgdp;
+    a_evaps -= zdtdt * t.zlsdcp * t.zgdp;
+    a_lvdcp += zdtdt * (t.zcondl2 - t.zevapr * t.zgdp);
+    a_lsdcp += zdtdt * (t.zcondi2 - t.zevaps * t.zgdp);
+    a_lude_in -= zdtdt * t.zgdp * w5;
+    a_lvdcp -= zdtdt * x.lude * t.zgdp * t.zfwat;
+    a_lsdcp -= zdtdt * x.lude * t.zgdp * (1.0 - t.zfwat);
+    a_fwat -= zdtdt * x.lude * t.zgdp * (t.zlvdcp - t.zlsdcp);
+    a_lsdcp += zdtdt * t.zrfreeze3 * t.zgdp;
+    a_lvdcp -= zdtdt * t.zrfreeze3 * t.zgdp;
+    a_rfreeze += zdtdt * (t.zlsdcp - t.zlvdcp) * t.zgdp;
+    a_gdp += zdqdt * (x.lude + t.zevapr + t.zevaps);
+    a_lude_in += zdqdt * t.zgdp;
+    a_evapr += zdqdt * t.zgdp;
+    a_evaps += zdqdt * t.zgdp;
+    a_condl -= zdqdt;
+    a_condi -= zdqdt;
+  }
+
+  // M^T: extra condensation to precipitation (cloudsc2ad.F90:1017-1063)
+  real_t a_qold = 0.0;
+  {
+    real_t zrfreeze2 = a_rfreeze;
+    real_t zsn = a_sfln, zrn = a_rfln;
+    real_t a_dq = a_condi * (1.0 - t.zfwatr2) * c.zqtmst + a_condl * t.zfwatr2 * c.zqtmst;
+    real_t zdr2 = (1.0 - t.zfwatr2) * zsn + t.zfwatr2 * zrn;
+    if (t.frz2) {
+      a_fwat += t.zdr2 * zrfreeze2;
+      zdr2 += t.zfwat * zrfreeze2;
+    }
+    a_dq += c.zcons2 * t.zdp * zdr2;
+    a_dp += c.zcons2 * t.zdq * zdr2;
+    if (t.dq_pos) {
+      if (c.lregcl) a_dq *= 0.7;
+      a_qold += a_dq;
+      a_qp1 -= a_dq;
+    }
+  }
+
+  // L^T: saturation adjustment (cuadjtqsad.F90:542-641)
+  {
+    real_t a_zqp = 0.0;
+#pragma unroll
+    for (int it = 1; it >= 0; --it) {
+      real_t den = t.a_den[it];
+      real_t tm4a = t.a_tm4[it];
+      real_t zcond1 = -a_qp1 + t.zaldcp * a_tp1;
+      a_qp1 += zcond1 / den;
+      real_t zqsat = -zcond1 / den;
+      real_t dqmq = (t.a_q[it] - t.a_qsat[it]) / (den * den);
+      zqsat -= zcond1 * dqmq * t.a_cor[it] * t.a_z2s[it];
+      real_t zcor = -zcond1 * dqmq * t.a_qsat[it] * t.a_z2s[it];
+      real_t z2s = -zcond1 * dqmq * t.a_qsat[it] * t.a_cor[it];
+      real_t ztarg = -2.0 * z2s * t.z5alcp / (tm4a * tm4a * tm4a);
+      zcor += zqsat * t.a_qsatu[it];
+      zqsat = zqsat * t.a_cor[it];
+      zqsat += zcor * c.retv * (t.a_cor[it] * t.a_cor[it]);
+      if (t.a_clip[it]) zqsat = 0.0;
+      real_t zfoeew = zqsat * t.zqp;
+      a_zqp += zqsat * t.a_foeew[it];
+      ztarg += zfoeew * t.z3es * (c.rtt - t.z4es) * t.a_foeew[it] / (tm4a * tm4a);
+      a_tp1 += ztarg;
+    }
+    a_pap -= a_zqp * (t.zqp * t.zqp);
+  }
+
+  // K^T: first-guess T and q (cloudsc2ad.F90:1076-1125)
+  {
+    a_qp1 += a_qold;
+    real_t zdqdt = c.ptsphy * a_qp1;
+    real_t zdtdt = c.ptsphy * a_tp1;
+    a_gdp -= zdtdt * (t.zlvdcp * t.zevapr + t.zlsdcp * t.zevaps + x.lude * w5 - (t.zlsdcp - t.zlvdcp) * t.zrfreeze1);
+    a_condl += zdtdt * t.zlvdcp;
+    a_condi += zdtdt * t.zlsdcp;
+    a_evapr -= zdtdt * t.zlvdcp * t.zgdp;
+    a_evaps -= zdtdt * t.zlsdcp * t.zgdp;
+    a_lvdcp += zdtdt * (t.zcondl1 - t.zevapr * t.zgdp);
+    a_lsdcp += zdtdt * (t.zcondi1 - t.zevaps * t.zgdp);
+    a_lude_in -= zdtdt * t.zgdp * w5;
+    a_lvdcp -= zdtdt * x.lude * t.zgdp * t.zfwat;
+    a_lsdcp -= zdtdt * x.lude * t.zgdp * (1.0 - t.zfwat);
+    a_fwat -= zdtdt * x.lude * t.zgdp * (t.zlvdcp - t.zlsdcp);
+    a_lsdcp += zdtdt * t.zrfreeze1 * t.zgdp;
+    a_lvdcp -= zdtdt * t.zrfreeze1 * t.zgdp;
+    a_rfreeze += zdtdt * (t.zlsdcp - t.zlvdcp) * t.zgdp;
+    a_gdp += zdqdt * (x.lude + t.zevapr + t.zevaps);
+    a_lude_in += zdqdt * t.zgdp;
+    a_evapr += zdqdt * t.zgdp;
+    a_evaps += zdqdt * t.zgdp;
+    a_condl -= zdqdt;
+    a_condi -= zdqdt;
+  }
+
+  // J^T: evaporation of precipitation (cloudsc2ad.F90:1152-1261)
+  real_t a_prtot = 0.0;
+  if (t.llo2) {
+    real_t zdpr = 0.0, zpreclr = 0.0, zb = 0.0, zbeta = 0.0, zqe = 0.0, a_dtgdp = 0.0;
+    // ice proportion
+    a_evaps -= a_sfln;
+    a_sfln += t.zdpr * a_evaps / t.zprtot;
+    zdpr += t.sfln2 * a_evaps / t.zprtot;
+    a_prtot -= t.zdpr * t.sfln2 * a_evaps / (t.zprtot * t.zprtot);
+    // warm proportion
+    a_evapr -= a_rfln;
+    a_rfln += t.zdpr * a_evapr / t.zprtot;
+    zdpr += t.rfln2 * a_evapr / t.zprtot;
+    a_prtot -= t.zdpr * t.rfln2 * a_evapr / (t.zprtot * t.zprtot);
+    // clear-sky flux
+    a_covptot += ya.covptot;
+    if (t.reset) { a_clc += a_covptot; a_covptot = 0.0; }
+    zdpr -= zpreclr;
+    if (t.dpr_clip) { zpreclr += zdpr; zdpr = 0.0; }
+    zb += t.covpclr * zdpr / t.zdtgdp;
+    a_covpclr += t.zb * zdpr / t.zdtgdp;
+    a_dtgdp -= t.covpclr * t.zb * zdpr / (t.zdtgdp * t.zdtgdp);
+    {
+      real_t dpk = x.paph_k1 - x.paph_k;
+      real_t g = c.ptsphy * c.rg * a_dtgdp / (dpk * dpk);
+      a_paph_k1 -= g;
+      a_paph_k += g;
+    }
+    // implicit solution
+    real_t den = 1.0 + t.zbeta * c.ptsphy * t.zcorqs;
+    zbeta += c.ptsphy * (x.qs - t.zqe) * zb / den;
+    a_qs += c.ptsphy * t.zbeta * zb / den;
+    zqe -= c.ptsphy * t.zbeta * zb / den;
+    a_corqs -= (c.ptsphy * c.ptsphy) * t.zbeta * (x.qs - t.zqe) * t.zbeta * zb / (den * den);
+    zbeta -= (c.ptsphy * c.ptsphy) * t.zbeta * (x.qs - t.zqe) * t.zcorqs * zb / (den * den);
+    // zbeta
+    real_t zxx = 0.5777 * (c.rg * c.rpecons / 5.09e-3) * pow(5.09e-3 * t.covpclr / (t.zpreclr1 * t.zsqp), 0.4223);
+    zpreclr += zxx * t.zsqp * zbeta / t.covpclr;
+    a_pap += (zxx * 0.5 * t.zpreclr1 * zbeta / sqrt(x.pap * x.paph_surf)) / t.covpclr;
+    a_paph_surf -= (zxx * 0.5 * t.zpreclr1 * t.zsqp * zbeta / x.paph_surf) / t.covpclr;
+    a_covpclr -= zxx * t.zpreclr1 * t.zsqp * zbeta / (t.covpclr * t.covpclr);
+    // zqe
+    real_t omc2 = t.omc * t.omc;
+    a_qs += zqe;
+    a_covpclr -= (x.qs - t.zqlim) * zqe / omc2;
+    a_qs -= t.covpclr * zqe / omc2;
+    a_qlim += t.covpclr * zqe / omc2;
+    a_clc -= 2.0 * (x.qs - t.zqlim) * t.covpclr * zqe / (omc2 * t.omc);
+    // zpreclr
+    a_covpclr += t.zprtot * zpreclr / t.covptot1;
+    a_prtot += t.covpclr * zpreclr / t.covptot1;
+    a_covptot -= t.zprtot * t.covpclr * zpreclr / (t.covptot1 * t.covptot1);
+    a_evapr = 0.0;
+    a_evaps = 0.0;
+  }
+
+  // I^T: new precipitation and autoconversion (cloudsc2ad.F90:1265-1356)
+  {
+    a_rfln += a_prtot;
+    a_sfln += a_prtot;
+    real_t zdr = (1.0 - t.zfwatr1) * a_sfln + t.zfwatr1 * a_rfln;
+    real_t zprr = 0.0, zprs = 0.0;
+    if (t.frz1) {
+      a_dp += a_rfreeze * c.zcons2 * t.zprr;
+      zprr += a_rfreeze * c.zcons2 * t.zdp;
+    }
+    zprr += c.zcons2 * t.zdp * zdr;
+    zprs += c.zcons2 * t.zdp * zdr;
+    a_dp += c.zcons2 * (t.zprr + t.zprs) * zdr;
+    if (t.cloudy) {
+      // ice
+      zprs -= a_qiwc;
+      a_qiwc += zprs;
+      real_t zinew = -zprs;
+      a_clc += zinew * t.zcldi * t.zexpdi;
+      real_t zcldi = zinew * t.clc * t.zexpdi;
+      real_t zdi = -zinew * t.clc * t.zcldi * t.zexpdi;
+      real_t cki = c.lregcl ? c.zckcodtia : c.zckcodti;
+      a_tp1 += cki * t.zexp1 * (1.0 - t.zexp2) * 0.025 * zdi;
+      zcldi += (cki * t.zexp1 * t.zexp2 * 2.0 * t.zcldi / (c.zlcrit_i * c.zlcrit_i)) * zdi;
+      a_qiwc += zcldi / t.clc;
+      a_clc -= t.zqiwc1 * zcldi / (t.clc * t.clc);
+      // liquid
+      zprr -= a_qlwc;
+      a_qlwc += zprr;
+      real_t zlnew = -zprr;
+      a_clc += zlnew * t.zcldl * t.zexpdl;
+      real_t zcldl = zlnew * t.clc * t.zexpdl;
+      real_t zdl = -zlnew * t.clc * t.zcldl * t.zexpdl;
+      real_t ck = c.lregcl ? c.zckcodtla : c.zckcodtl;
+      zcldl += (2.0 * ck / (c.zlcrit_l * c.zlcrit_l)) * t.zexp3 * t.zcldl * zdl;
+      a_qlwc += zcldl / t.clc;
+      a_clc -= t.zqlwc1 * zcldl / (t.clc * t.clc);
+    }
+  }
+
+  // H^T: melting of incoming snow (cloudsc2ad.F90:1362-1400)
+  real_t a_sfl = 0.0, a_rfl = 0.0;
+  if (t.melt) {
+    real_t zsnmlt = -a_tp1 / t.zcons;
+    real_t zcons = (a_tp1 * t.zsnmlt) / (t.zcons * t.zcons);
+    a_sfl += a_sfln;
+    zsnmlt -= a_sfln;
+    a_rfl += a_rfln;
+    zsnmlt += a_rfln;
+    real_t zz2s = 0.0;
+    if (t.melt_all) a_sfl += zsnmlt; else zz2s += zsnmlt;
+    if (t.warm2) {
+      a_tp1 += t.zcons * zz2s;
+      zcons += (t.ztp2 - c.zmeltp2) * zz2s;
+    }
+    a_dp += c.zcons2 * zcons / t.zlfdcp;
+    a_lfdcp -= c.zcons2 * t.zdp * zcons / (t.zlfdcp * t.zlfdcp);
+  } else {
+    a_sfl += a_sfln;
+    a_rfl += a_rfln;
+  }
+
+  // G^T: overlap (cloudsc2ad.F90:1407-1418)
+  if (t.covpclr1 < 0.0) a_covpclr = 0.0;
+  a_covptot += a_covpclr;
+  a_clc -= a_covpclr;
+  if (t.newmax) { a_clc += a_covptot; a_covptot = 0.0; }
+
+  // F^T (cloudsc2ad.F90:1425-1441)
+  real_t a_qc = 0.0;
+  a_qiwc += a_condi * c.zqtmst;  a_i -= a_condi * c.zqtmst;
+  a_qlwc += a_condl * c.zqtmst;  a_l -= a_condl * c.zqtmst;
+  a_qc += a_qiwc * (1.0 - t.zfwat);
+  a_fwat -= a_qiwc * t.zqc3;
+  a_qc += a_qlwc * t.zfwat;
+  a_fwat += a_qlwc * t.zqc3;
+
+  // E^T: subsidence (cloudsc2ad.F90:1447-1495)
+  real_t a_foeew = 0.0;
+  {
+    real_t zdqc = -a_qc, zdqsdz = 0.0, zrho = 0.0;
+    if (t.llo3) {
+      if (c.lregcl) zdqc *= 0.1;
+      zdqsdz += zdqc * c.ptsphy * (x.mfu + x.mfd) * t.zfac4;
+      a_mfu += zdqc * c.ptsphy * t.zdqsdz * t.zfac4;
+      a_mfd += zdqc * c.ptsphy * t.zdqsdz * t.zfac4;
+      zrho -= zdqc * t.zdqc * t.zfac4;
+    } else {
+      a_qc += zdqc;
+    }
+    real_t dtdzmo = zdqsdz * t.zdqsdtemp;
+    a_dqsdtemp += zdqsdz * t.dtdzmo;
+    real_t zrodqsdp = -zdqsdz * c.rg;
+    real_t zldcp = -dtdzmo * (c.rg * t.zrodqsdp + t.dtdzmo * t.zdqsdtemp) * t.zfac3;
+    zrodqsdp -= dtdzmo * c.rg * t.zldcp * t.zfac3;
+    a_dqsdtemp -= dtdzmo * t.dtdzmo * t.zldcp * t.zfac3;
+    a_fwat += zldcp * (t.zlvdcp - t.zlsdcp);
+    a_lvdcp += zldcp * t.zfwat;
+    a_lsdcp += zldcp * (1.0 - t.zfwat);
+    zrho -= zrodqsdp * x.qs * t.zfac2;
+    a_qs -= zrodqsdp * t.zrho * t.zfac2;
+    a_pap += zrodqsdp * t.zrho * x.qs * (t.zfac2 * t.zfac2);
+    a_foeew -= zrodqsdp * t.zrho * x.qs * c.retv * (t.zfac2 * t.zfac2);
+    a_pap += zrho * t.zfac1;
+    a_tp1 -= zrho * x.pap / t.ztp2 * t.zfac1;
+  }
+
+  // D^T: convective component (cloudsc2ad.F90:1501-1526)
+  {
+    real_t zlude = 0.0;
+    if (t.llo1) {
+      zlude += a_qc;
+      zlude += ((1.0 - t.zclc) / x.lu_k1) * t.zexpl * a_clc;
+      a_lu_k1 -= ((1.0 - t.zclc) * t.zlude / (x.lu_k1 * x.lu_k1)) * t.zexpl * a_clc;
+      a_clc = a_clc * (1.0 - (1.0 - t.zexpl));
+    }
+    a_lude_in += c.ptsphy * t.zgdp * zlude;
+    a_gdp += c.ptsphy * x.lude * zlude;
+    real_t dpk = x.paph_k1 - x.paph_k;
+    real_t g = c.rg * a_gdp / (dpk * dpk);
+    a_paph_k1 -= g;
+    a_paph_k += g;
+  }
+
+  // C^T: cloud cover (cloudsc2ad.F90:1532-1582)
+  real_t a_qsat = 0.0, a_qcrit = 0.0;
+  {
+    real_t zqt = 0.0;
+    if (t.regime == 0) {
+      // nothing propagates
+    } else if (t.regime == 1) {
+      a_qsat += (1.0 - k.zscalm) * a_qc;
+      a_qcrit -= (1.0 - k.zscalm) * a_qc;
+    } else {
+      real_t zqpd = k.zscalm * a_qc * (t.zclc * t.zclc);
+      real_t zqcd = (1.0 - k.zscalm) * a_qc * (t.zclc * t.zclc);
+      a_clc += (k.zscalm * t.zqpd + (1.0 - k.zscalm) * t.zqcd) * 2.0 * t.zclc * a_qc;
+      if (c.lregcl) {
+        real_t zrat = t.zqpd / t.zqcd;
+        real_t w = 1.0 - k.zscalm * (1.0 - zrat);
+        real_t zyyy = fmin(0.3, 3.5 * sqrt(zrat * (w * w * w)) / (1.0 - k.zscalm));
+        a_clc = zyyy * a_clc;
+      }
+      real_t h = 0.5 / t.zsqrt;
+      zqpd -= h * a_clc / t.zden;
+      zqcd += h * (t.zqpd * a_clc) / (t.zden * t.zden);
+      zqt -= h * (t.zqpd * k.zscalm * a_clc) / (t.zden * t.zden);
+      a_qcrit += h * (t.zqpd * k.zscalm * a_clc) / (t.zden * t.zden);
+      a_qsat += zqcd;
+      a_qcrit -= zqcd;
+      a_qsat += zqpd;
+      zqt -= zqpd;
+    }
+    a_qp1 += zqt;
+    a_l += zqt;
+    a_i += zqt;
+  }
+
+  // B^T and A^T (cloudsc2ad.F90:1596-1664)
+  {
+    a_qsat += a_qcrit * t.zcrh2;
+    a_qs += a_qsat * t.zsupsat;
+    real_t zsupsat = a_qsat * x.qs;
+    if (t.below_rtice) a_tp1 -= zsupsat * 3.e-03;
+    if (t.qlim_is_qs) a_qs += a_qlim; else a_qp1 += a_qlim;
+
+    a_dqsdtemp += c.zcons3 * a_corqs;
+    a_qs += t.zfac * t.zcor * a_dqsdtemp;
+    real_t zcor = t.zfac * x.qs * a_dqsdtemp;
+    real_t zfac = t.zcor * x.qs * a_dqsdtemp;
+    real_t zesdp = c.retv * zcor * (t.zcor * t.zcor);
+    real_t zfacw = t.zfwat * zfac;
+    a_fwat += t.zfacw * zfac;
+    real_t zfaci = (1.0 - t.zfwat) * zfac;
+    a_fwat -= t.zfaci * zfac;
+    a_tp1 -= 2.0 * c.r5ies * zfaci / (t.tm4i * t.tm4i * t.tm4i);
+    a_tp1 -= 2.0 * c.r5les * zfacw / (t.tm4l * t.tm4l * t.tm4l);
+    if (t.esdp_clip) zesdp = 0.0;
+    a_foeew += zesdp / x.pap;
+    a_pap -= zesdp * t.zfoeew / (x.pap * x.pap);
+    real_t z3es, z4es, tm4;
+    if (t.cold) { z3es = c.r3ies; z4es = c.r4ies; tm4 = t.tm4i; }
+    else        { z3es = c.r3les; z4es = c.r4les; tm4 = t.tm4l; }
+    a_tp1 += z3es * (c.rtt - z4es) * a_foeew * t.zfoeew / (tm4 * tm4);
+    if (t.cold) a_tp1 += 0.545 * 0.17 * a_fwat * t.zcosh2r;
+  }
+
+  // thermodynamic constants and first guess (cloudsc2ad.F90:1701-1738)
+  {
+    real_t zzz = c.rlvtt * a_lvdcp + c.rlstt * a_lsdcp + c.rlmlt * a_lfdcp;
+    if (!c.rvtmp2_zero) a_qp1 -= zzz * c.rcpd * c.rvtmp2 * (t.zzz * t.zzz);
+    a_paph_k1 += a_dp;
+    a_paph_k -= a_dp;
+  }
+
+  ax.paph_k = a_paph_k;
+  ax.paph_k1 = a_paph_k1;
+  ax.paph_surf = a_paph_surf;
+  ax.pap = a_pap;
+  ax.q = a_qp1;
+  ax.qs = a_qs;
+  ax.t = a_tp1;
+  ax.l = a_l;
+  ax.i = a_i;
+  ax.lude = a_lude_in;
+  ax.lu_k1 = a_lu_k1;
+  ax.mfu = a_mfu;
+  ax.mfd = a_mfd;
+  ax.gt = c.ptsphy * a_tp1;
+  ax.gq = c.ptsphy * a_qp1;
+  ax.gl = c.ptsphy * a_l;
+  ax.gi = c.ptsphy * a_i;
+  ax.supsat = c.ptsphy * a_qp1;  // the reference ASSIGNS PTSPHY*zqp1 (cloudsc2ad.F90:1733)
+
+  acy.rfl = a_rfl;
+  acy.sfl = a_sfl;
+  acy.covptot = a_covptot;
+}
+
+}  // namespace cloudsc2

@@ -1,0 +1,213 @@
+"""Host-side mirror of the reference's driver interface for the CLOUDSC2 hot path.
+
+``cloudsc_driver``, ``cloudsc_driver_tl`` and ``cloudsc_driver_ad`` take the argument list of the reference's
+``CLOUDSC_DRIVER{,_TL,_AD}`` (src/cloudsc2_nl/cloudsc_driver_mod.F90:22-30; the TL and AD drivers share it) on numpy
+arrays in the GLOBAL_STATE layout and dispatch through the C ABI to the HIP kernels -- the same calls the Fortran
+drivers in ``fortran/`` make through ISO_C_BINDING.  ``DeviceState`` keeps the whole state resident in HBM (torch
+tensors are used only as device memory) and launches the kernels on a HIP stream; it is what ``bench.py`` times.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import binding as B
+from .state import PLANE_Q, PLANE_QI, PLANE_QL, PLANE_QV, PLANE_T, Cloudsc2State, nblocks_of
+
+_dp = C.POINTER(C.c_double)
+
+
+def _ptr(a: np.ndarray):
+    if a.dtype != np.float64 or not a.flags["C_CONTIGUOUS"]:
+        raise ValueError("state arrays must be C-contiguous float64")
+    return a.ctypes.data_as(_dp)
+
+
+def _host_args(prm: B.Params, nproma, nlev, ngptot, ptsphy, arrays):
+    return [C.byref(prm), int(nproma), int(nlev), int(ngptot), float(ptsphy)] + [_ptr(a) for a in arrays]
+
+
+def cloudsc_driver(prm: B.Params, numomp, nproma, nlev, ngptot, ngptotg, ptsphy, pt, pq, tendency_cml, tendency_loc, pap,
+                   paph, plu, plude, pmfu, pmfd, pa, pclv, psupsat, pcovptot, pfplsl, pfplsn, pfhpsl, pfhpsn) -> float:
+    """CLOUDSC_DRIVER (cloudsc_driver_mod.F90:22-125).  ``tendency_cml`` / ``tendency_loc`` are the B_CML / B_LOC
+    buffers the reference's STATE_TYPE arrays view.  ``numomp`` and ``ngptotg`` are accepted for signature parity
+    (the block loop is one GPU launch).  Returns the kernel time in ms; outputs are written in place."""
+    del numomp, ngptotg
+    ms = C.c_double(0.0)
+    arrays = [pt, pq, tendency_cml, tendency_loc, pap, paph, plu, plude, pmfu, pmfd, pa, pclv, psupsat, pcovptot, pfplsl,
+              pfplsn, pfhpsl, pfhpsn]
+    B.check(B.lib.cloudsc2_nl_run(*_host_args(prm, nproma, nlev, ngptot, ptsphy, arrays), C.byref(ms)))
+    return ms.value
+
+
+def cloudsc_driver_tl(prm: B.Params, numomp, nproma, nlev, ngptot, ngptotg, ptsphy, pt, pq, tendency_cml, tendency_loc,
+                      pap, paph, plu, plude, pmfu, pmfd, pa, pclv, psupsat, pcovptot, pfplsl, pfplsn, pfhpsl, pfhpsn):
+    """CLOUDSC_DRIVER_TL (cloudsc_driver_tl_mod.F90:33-314): returns (znormg[10], passed, itest, kernel_ms)."""
+    del numomp, ngptotg
+    ms = C.c_double(0.0)
+    zn = (C.c_double * 10)()
+    arrays = [pt, pq, tendency_cml, tendency_loc, pap, paph, plu, plude, pmfu, pmfd, pa, pclv, psupsat, pcovptot, pfplsl,
+              pfplsn, pfhpsl, pfhpsn]
+    B.check(B.lib.cloudsc2_tl_taylor_run(*_host_args(prm, nproma, nlev, ngptot, ptsphy, arrays), zn, C.byref(ms)))
+    znormg = np.array(zn[:], dtype=np.float64)
+    ok, itest = B.taylor_verdict(znormg)
+    return znormg, ok, itest, ms.value
+
+
+def cloudsc_driver_ad(prm: B.Params, numomp, nproma, nlev, ngptot, ngptotg, ptsphy, pt, pq, tendency_cml, tendency_loc,
+                      pap, paph, plu, plude, pmfu, pmfd, pa, pclv, psupsat, pcovptot, pfplsl, pfplsn, pfhpsl, pfhpsn):
+    """CLOUDSC_DRIVER_AD (cloudsc_driver_ad_mod.F90:22-297): returns (znormg, ok, kernel_ms)."""
+    del numomp, ngptotg
+    ms = C.c_double(0.0)
+    zn = C.c_double(0.0)
+    arrays = [pt, pq, tendency_cml, tendency_loc, pap, paph, plu, plude, pmfu, pmfd, pa, pclv, psupsat, pcovptot, pfplsl,
+              pfplsn, pfhpsl, pfhpsn]
+    B.check(B.lib.cloudsc2_ad_symmetry_run(*_host_args(prm, nproma, nlev, ngptot, ptsphy, arrays), C.byref(zn), C.byref(ms)))
+    return zn.value, B.adjoint_verdict(zn.value), ms.value
+
+
+def run_state(prm: B.Params, st: Cloudsc2State, which: str = "nl"):
+    """Convenience: run one of the three drivers on a Cloudsc2State (outputs written into it)."""
+    fn = {"nl": cloudsc_driver, "tl": cloudsc_driver_tl, "ad": cloudsc_driver_ad}[which]
+    return fn(prm, 1, st.nproma, st.nlev, st.ngptot, st.ngptot, st.ptsphy, *st.driver_arrays())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# HBM-resident state
+# ---------------------------------------------------------------------------------------------------------------------
+def _fld(t, offset_elems: int, stride: int) -> B.Field:
+    f = B.Field()
+    f.ptr = t.data_ptr() + 8 * offset_elems
+    f.block_stride = stride
+    return f
+
+
+class FlatFields:
+    """16 input-shaped or 10 output-shaped flat (NBLOCKS, NLEVx, NPROMA) device arrays, e.g. the TL increments."""
+
+    def __init__(self, kind: str, nb: int, nlev: int, nproma: int, device, zero: bool = True):
+        import torch
+
+        self.kind = kind
+        names = B.IN_NAMES if kind == "in" else B.OUT_NAMES
+        half = {"paph"} if kind == "in" else {"fplsl", "fplsn", "fhpsl", "fhpsn"}
+        mk = torch.zeros if zero else torch.empty
+        self.t = {n: mk((nb, nlev + (1 if n in half else 0), nproma), dtype=torch.float64, device=device) for n in names}
+        self.nlev, self.nproma = nlev, nproma
+
+    def block(self):
+        blk = B.Inputs() if self.kind == "in" else B.Outputs()
+        for n, t in self.t.items():
+            setattr(blk, n, _fld(t, 0, t.shape[1] * t.shape[2]))
+        return blk
+
+    def zero_(self):
+        for t in self.t.values():
+            t.zero_()
+
+
+class DeviceState:
+    """GLOBAL_STATE resident in HBM.  torch is used for allocation, streams and H2D/D2H only."""
+
+    FULL = ("PT", "PQ", "PAP", "PLU", "PLUDE", "PMFU", "PMFD", "PA", "PSUPSAT", "PCOVPTOT")
+    HALF = ("PAPH", "PFPLSL", "PFPLSN", "PFHPSL", "PFHPSN")
+
+    def __init__(self, st: Cloudsc2State, device="cuda:0"):
+        import torch
+
+        self.torch = torch
+        self.device = torch.device(device)
+        self.nproma, self.nlev, self.ngptot, self.ptsphy = st.nproma, st.nlev, st.ngptot, st.ptsphy
+        self.nb = nblocks_of(st.ngptot, st.nproma)
+        for n in self.FULL + self.HALF + ("B_CML", "B_LOC", "PCLV"):
+            setattr(self, n, torch.from_numpy(getattr(st, n)).to(self.device))
+        self.QSAT = torch.zeros_like(self.PT)
+        self._keep = []
+
+    # -- argument blocks in the driver-array -> kernel-dummy mapping of cloudsc_driver_mod.F90:94-107 --
+    def traj_inputs(self, with_qsat: bool = False) -> B.Inputs:
+        S, H, P = self.nproma * self.nlev, self.nproma * (self.nlev + 1), self.nproma * self.nlev
+        i = B.Inputs()
+        i.paph = _fld(self.PAPH, 0, H); i.pap = _fld(self.PAP, 0, S); i.q = _fld(self.PQ, 0, S)
+        i.qsat = _fld(self.QSAT, 0, S) if with_qsat else B.Field()
+        i.t = _fld(self.PT, 0, S)
+        i.l = _fld(self.PCLV, 0 * P, 5 * S); i.i = _fld(self.PCLV, 1 * P, 5 * S)
+        i.lude = _fld(self.PLUDE, 0, S); i.lu = _fld(self.PLU, 0, S)
+        i.mfu = _fld(self.PMFU, 0, S); i.mfd = _fld(self.PMFD, 0, S)
+        i.gtent = _fld(self.B_CML, PLANE_T * P, 8 * S); i.gtenq = _fld(self.B_CML, PLANE_Q * P, 8 * S)
+        i.gtenl = _fld(self.B_CML, PLANE_QL * P, 8 * S); i.gteni = _fld(self.B_CML, PLANE_QI * P, 8 * S)
+        i.supsat = _fld(self.PSUPSAT, 0, S)
+        return i
+
+    def traj_outputs(self) -> B.Outputs:
+        S, H, P = self.nproma * self.nlev, self.nproma * (self.nlev + 1), self.nproma * self.nlev
+        o = B.Outputs()
+        o.tent = _fld(self.B_LOC, PLANE_T * P, 8 * S); o.tenq = _fld(self.B_LOC, PLANE_Q * P, 8 * S)
+        o.tenl = _fld(self.B_LOC, PLANE_QL * P, 8 * S); o.teni = _fld(self.B_LOC, PLANE_QI * P, 8 * S)
+        o.clc = _fld(self.PA, 0, S); o.covptot = _fld(self.PCOVPTOT, 0, S)
+        o.fplsl = _fld(self.PFPLSL, 0, H); o.fplsn = _fld(self.PFPLSN, 0, H)
+        o.fhpsl = _fld(self.PFHPSL, 0, H); o.fhpsn = _fld(self.PFHPSN, 0, H)
+        return o
+
+    def zero_plane(self) -> B.Field:
+        # TENDENCY_LOC(IBL)%cld(:,:,NCLV)=0 (cloudsc_driver_mod.F90:88): plane QV of B_LOC
+        S = self.nproma * self.nlev
+        return _fld(self.B_LOC, PLANE_QV * S, 8 * S)
+
+    def _stream(self, stream):
+        s = stream if stream is not None else self.torch.cuda.current_stream(self.device)
+        return C.c_void_p(s.cuda_stream)
+
+    # -- kernel launches (asynchronous on `stream`) --
+    def satur(self, prm: B.Params, stream=None):
+        i = self.traj_inputs(True)
+        B.check(B.lib.cloudsc2_satur_launch(C.byref(prm), self.nproma, self.nlev, self.ngptot, i.pap, i.t, i.qsat,
+                                            self._stream(stream)))
+
+    def nl(self, prm: B.Params, stream=None, fused_satur: bool = True, pert_lambda: float = 0.0, outputs: B.Outputs | None = None):
+        """SATUR + CLOUDSC2 over all blocks = the body of cloudsc_driver_mod.F90:82-111."""
+        i = self.traj_inputs(not fused_satur)
+        o = outputs if outputs is not None else self.traj_outputs()
+        zp = self.zero_plane() if outputs is None else B.Field()
+        B.check(B.lib.cloudsc2_nl_launch(C.byref(prm), self.ptsphy, self.nproma, self.nlev, self.ngptot, C.byref(i),
+                                         C.byref(o), zp, float(pert_lambda), self._stream(stream)))
+
+    def tl(self, prm: B.Params, pert_in: FlatFields, pert_out: FlatFields, stream=None, fused_satur: bool = False,
+           store_traj: bool = True):
+        i = self.traj_inputs(not fused_satur)
+        o = self.traj_outputs() if store_traj else B.Outputs()
+        di, do = pert_in.block(), pert_out.block()
+        B.check(B.lib.cloudsc2_tl_launch(C.byref(prm), self.ptsphy, self.nproma, self.nlev, self.ngptot, C.byref(i),
+                                         C.byref(o), C.byref(di), C.byref(do), self._stream(stream)))
+
+    def ad(self, prm: B.Params, adj_in: FlatFields, adj_out: FlatFields, scratch, stream=None, fused_satur: bool = False):
+        i = self.traj_inputs(not fused_satur)
+        o = self.traj_outputs()
+        ai, ao = adj_in.block(), adj_out.block()
+        B.check(B.lib.cloudsc2_ad_launch(C.byref(prm), self.ptsphy, self.nproma, self.nlev, self.ngptot, C.byref(i),
+                                         C.byref(o), C.byref(ai), C.byref(ao), C.c_void_p(scratch.data_ptr()),
+                                         self._stream(stream)))
+
+    def increments(self, zero_supsat: bool = False) -> FlatFields:
+        """dx = 0.01 * x for the 16 inputs (cloudsc_driver_tl_mod.F90:156-171); ZSUPSAT = 0 in the adjoint test
+        (cloudsc_driver_ad_mod.F90:139)."""
+        ff = FlatFields("in", self.nb, self.nlev, self.nproma, self.device, zero=False)
+        src = {"paph": self.PAPH, "pap": self.PAP, "q": self.PQ, "qsat": self.QSAT, "t": self.PT,
+               "l": self.PCLV[:, 0], "i": self.PCLV[:, 1], "lude": self.PLUDE, "lu": self.PLU, "mfu": self.PMFU,
+               "mfd": self.PMFD, "gtent": self.B_CML[:, PLANE_T], "gtenq": self.B_CML[:, PLANE_Q],
+               "gtenl": self.B_CML[:, PLANE_QL], "gteni": self.B_CML[:, PLANE_QI], "supsat": self.PSUPSAT}
+        for n, s in src.items():
+            if n == "supsat" and zero_supsat:
+                ff.t[n].zero_()
+            else:
+                self.torch.mul(s, 0.01, out=ff.t[n])
+        return ff
+
+    def new_scratch(self):
+        return self.torch.empty((self.nb, self.nlev, self.nproma), dtype=self.torch.float64, device=self.device)
+
+    def download(self, st: Cloudsc2State) -> Cloudsc2State:
+        for n in ("B_LOC", "PA", "PCOVPTOT", "PFPLSL", "PFPLSN", "PFHPSL", "PFHPSN"):
+            getattr(st, n)[...] = getattr(self, n).cpu().numpy()
+        return st

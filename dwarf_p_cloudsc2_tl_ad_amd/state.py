@@ -1,0 +1,240 @@
+"""GLOBAL_STATE of the CLOUDSC2 dwarf in the reference's NPROMA-blocked layout, plus the synthetic atmosphere.
+
+Layout (reference: src/common/module/cloudsc2_array_state_mod.F90:26-151).  Fortran ``F(NPROMA, NLEV, NBLOCKS)``
+is held here as a C-ordered numpy/torch array of shape ``(NBLOCKS, NLEV, NPROMA)`` -- the same bytes.  The AoSoA
+tendency buffers ``B_CML/B_LOC(NPROMA, NLEV, 8, NBLOCKS)`` are ``(NBLOCKS, 8, NLEV, NPROMA)`` with plane order
+T=0, A=1, Q=2, CLD(QL, QI, QR, QS, QV)=3..7 (:145-148); ``PCLV(NPROMA, NLEV, 5, NBLOCKS)`` is
+``(NBLOCKS, 5, NLEV, NPROMA)``.
+
+``config-files/input.h5`` is not distributed with the reference checkout (``.MISSING_LARGE_BLOBS``), so the
+inputs are a deterministic synthetic atmosphere of 100 distinct columns that is tiled periodically
+to NGPTOT columns exactly like ``expand_r2`` (src/common/module/expand_mod.F90:270-302): column g (0-based) holds
+table column ``g mod 100``; the tail of the last block is zero.
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+
+import numpy as np
+
+KLON_TABLE = 100  # number of distinct columns, = KLON of the reference's input.h5 / reference.h5
+NLEV_DEFAULT = 137
+
+# plane indices inside B_CML / B_LOC and PCLV (0-based)
+PLANE_T, PLANE_A, PLANE_Q, PLANE_QL, PLANE_QI, PLANE_QR, PLANE_QS, PLANE_QV = range(8)
+NCLDQL, NCLDQI = 0, 1
+
+
+def nblocks_of(ngptot: int, nproma: int) -> int:
+    # NGPBLKS = (NGPTOT / NPROMA) + MIN(MOD(NGPTOT,NPROMA), 1)   (cloudsc_driver_mod.F90:64)
+    return ngptot // nproma + min(ngptot % nproma, 1)
+
+
+def column_range(ngptotg: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous sub-range of the global columns owned by ``rank`` -- the reference's MPI split
+    (src/cloudsc2_nl/dwarf_cloudsc.F90:66-69): NGPTOT = ceil(NGPTOTG/NUMPROC), last rank takes the remainder."""
+    per = (ngptotg - 1) // world + 1
+    start = min(rank * per, ngptotg)
+    stop = min(start + per, ngptotg)
+    return start, stop
+
+
+def synthetic_table(nlev: int = NLEV_DEFAULT, ncol: int = KLON_TABLE, consts: dict | None = None) -> dict:
+    """100 distinct columns, each field shaped (NLEV or NLEV+1, ncol) like the (KLEV, KLON) datasets of input.h5.
+
+    Recipe of SURVEY.md 8d: every column carries cloud and precipitates (the reference's Taylor test STOPs on a
+    block without active statistics), none is near-trivial (the adjoint test is relative per column).
+    """
+    c = consts or {}
+    rd, rv = c.get("rd", 287.0597), c.get("rv", 461.5250)
+    rtt = c.get("rtt", 273.16)
+    r2es = 611.21 * rd / rv
+    r3les, r4les = 17.502, 32.19
+
+    ig = np.arange(ncol, dtype=np.int64)
+    h1 = ((37 * ig) % 100) / 100.0
+    h2 = ((61 * ig + 13) % 100) / 100.0
+    h3 = ((89 * ig + 7) % 100) / 100.0
+
+    k = np.arange(nlev + 1, dtype=np.float64)
+    ps = 101325.0
+    paph_1d = 1.0 + (ps - 1.0) * (k / nlev) ** 2.2
+    pap_1d = 0.5 * (paph_1d[:-1] + paph_1d[1:])
+    paph = np.repeat(paph_1d[:, None], ncol, axis=1)
+    pap = np.repeat(pap_1d[:, None], ncol, axis=1)
+    eta = pap / ps
+
+    t = np.maximum(205.0 + 10.0 * h2[None, :], (255.0 + 45.0 * h1[None, :]) * eta**0.19)
+    rh = 0.35 + (0.72 + 0.1 * h3[None, :]) * np.exp(-(((eta - 0.3 - 0.5 * h2[None, :]) / 0.18) ** 2))
+    e_liq = r2es * np.exp(r3les * (t - rtt) / (t - r4les))
+    q = rh * np.minimum(0.5, e_liq / pap)
+    moist = rh > 0.8
+    ql = 1e-7 * eta + np.where(moist, 2e-5 * h1[None, :] * eta, 0.0)
+    qi = 1e-7 * (1.0 - eta) + np.where(moist, 1e-5 * (1.0 - h1[None, :]), 0.0)
+
+    conv = (h3[None, :] > 0.6) & (eta > 0.35) & (eta < 0.9)
+    plu = np.where(conv, 3e-4 * h3[None, :], 0.0)
+    pmfu = np.where(conv, 0.05 * h3[None, :], 0.0)
+    pmfd = np.where(conv, -0.01 * h3[None, :], 0.0)
+    plude = np.where(conv & (eta < 0.5), 1e-6 * h3[None, :], 0.0)
+
+    zeros = np.zeros((nlev, ncol))
+    tend_t = np.repeat((1e-5 * (h1 - 0.5))[None, :], nlev, axis=0)
+    tend_q = np.repeat((1e-9 * (h2 - 0.5))[None, :], nlev, axis=0)
+    return {
+        "PT": t, "PQ": q, "PAP": pap, "PAPH": paph, "PLU": plu, "PLUDE": plude, "PMFU": pmfu, "PMFD": pmfd,
+        "PA": zeros.copy(), "PCLV_QL": ql, "PCLV_QI": qi, "PSUPSAT": zeros.copy(),
+        "TENDENCY_CML_T": tend_t, "TENDENCY_CML_Q": tend_q, "TENDENCY_CML_QL": zeros.copy(),
+        "TENDENCY_CML_QI": zeros.copy(), "PTSPHY": 3600.0,
+    }
+
+
+def random_table(nlev: int, ncol: int, seed: int) -> dict:
+    """Randomised variant of the synthetic atmosphere for parity tests: same structure, seeded perturbations of
+    every field (including non-zero PSUPSAT and cloud tendencies) so that more branch combinations are visited."""
+    rng = np.random.default_rng(seed)
+    tab = synthetic_table(nlev, ncol)
+    u = lambda shape, a, b: rng.uniform(a, b, size=shape)  # noqa: E731
+    tab["PT"] = tab["PT"] + u((nlev, ncol), -3.0, 3.0)
+    tab["PQ"] = tab["PQ"] * u((nlev, ncol), 0.7, 1.25)
+    tab["PCLV_QL"] = tab["PCLV_QL"] * u((nlev, ncol), 0.2, 3.0)
+    tab["PCLV_QI"] = tab["PCLV_QI"] * u((nlev, ncol), 0.2, 3.0)
+    tab["PLU"] = tab["PLU"] * u((nlev, ncol), 0.5, 1.5)
+    tab["PLUDE"] = tab["PLUDE"] * u((nlev, ncol), 0.0, 2.0)
+    tab["PMFU"] = tab["PMFU"] * u((nlev, ncol), 0.5, 1.5)
+    tab["PMFD"] = tab["PMFD"] * u((nlev, ncol), 0.5, 1.5)
+    tab["PSUPSAT"] = tab["PQ"] * u((nlev, ncol), 0.0, 1e-3)
+    tab["TENDENCY_CML_T"] = tab["TENDENCY_CML_T"] * u((nlev, ncol), -1.0, 2.0)
+    tab["TENDENCY_CML_Q"] = tab["TENDENCY_CML_Q"] * u((nlev, ncol), -1.0, 2.0)
+    tab["TENDENCY_CML_QL"] = tab["PCLV_QL"] * u((nlev, ncol), -1e-5, 1e-5)
+    tab["TENDENCY_CML_QI"] = tab["PCLV_QI"] * u((nlev, ncol), -1e-5, 1e-5)
+    # surface pressure varies per column; keep PAP between the half levels
+    scale = u((1, ncol), 0.93, 1.03)
+    tab["PAPH"] = tab["PAPH"] * scale
+    tab["PAP"] = tab["PAP"] * scale
+    return tab
+
+
+def ceta_from_table(tab: dict) -> np.ndarray:
+    # YRECLD%CETA(JK) = PAP(1,JK,1)/PAPH(1,KLEV+1,1): column 1 of block 1 only (dwarf_cloudsc.F90:100-102)
+    return np.ascontiguousarray(tab["PAP"][:, 0] / tab["PAPH"][-1, 0])
+
+
+def _tile(field2d: np.ndarray, nproma: int, ngptot: int, col0: int = 0) -> np.ndarray:
+    """(NLEVx, ncol) table -> (NBLOCKS, NLEVx, NPROMA), periodic in the global column index (expand_mod.F90:283-296);
+    ``col0`` is the global index of this rank's first column."""
+    nlevx, ncol = field2d.shape
+    nb = nblocks_of(ngptot, nproma)
+    out = np.zeros((nb * nproma, nlevx), dtype=np.float64)
+    idx = (col0 + np.arange(ngptot)) % ncol
+    out[:ngptot, :] = field2d.T[idx, :]
+    return np.ascontiguousarray(out.reshape(nb, nproma, nlevx).transpose(0, 2, 1))
+
+
+@dataclasses.dataclass
+class Cloudsc2State:
+    """Host-side GLOBAL_STATE (numpy, fp64).  Field names are the reference's."""
+
+    nproma: int
+    nlev: int
+    ngptot: int
+    ptsphy: float
+    PT: np.ndarray
+    PQ: np.ndarray
+    B_CML: np.ndarray
+    B_LOC: np.ndarray
+    PAP: np.ndarray
+    PAPH: np.ndarray
+    PLU: np.ndarray
+    PLUDE: np.ndarray
+    PMFU: np.ndarray
+    PMFD: np.ndarray
+    PA: np.ndarray
+    PCLV: np.ndarray
+    PSUPSAT: np.ndarray
+    PCOVPTOT: np.ndarray
+    PFPLSL: np.ndarray
+    PFPLSN: np.ndarray
+    PFHPSL: np.ndarray
+    PFHPSN: np.ndarray
+
+    @property
+    def nblocks(self) -> int:
+        return nblocks_of(self.ngptot, self.nproma)
+
+    DRIVER_ORDER = ("PT", "PQ", "B_CML", "B_LOC", "PAP", "PAPH", "PLU", "PLUDE", "PMFU", "PMFD", "PA", "PCLV",
+                    "PSUPSAT", "PCOVPTOT", "PFPLSL", "PFPLSN", "PFHPSL", "PFHPSN")
+
+    def driver_arrays(self):
+        """Arrays in the argument order of CLOUDSC_DRIVER (cloudsc_driver_mod.F90:22-30)."""
+        return [getattr(self, n) for n in self.DRIVER_ORDER]
+
+    def copy(self) -> "Cloudsc2State":
+        kw = {f.name: getattr(self, f.name) for f in dataclasses.fields(self)}
+        for k, v in kw.items():
+            if isinstance(v, np.ndarray):
+                kw[k] = v.copy()
+        return Cloudsc2State(**kw)
+
+    # output fields the reference validates (cloudsc2_array_state_mod.F90:246-256), as flat views
+    def outputs(self) -> dict:
+        return {
+            "PCOVPTOT": self.PCOVPTOT, "PFPLSL": self.PFPLSL, "PFPLSN": self.PFPLSN, "PFHPSL": self.PFHPSL,
+            "PFHPSN": self.PFHPSN, "PA": self.PA,
+            "TENDENCY_LOC_T": self.B_LOC[:, PLANE_T], "TENDENCY_LOC_Q": self.B_LOC[:, PLANE_Q],
+            "TENDENCY_LOC_QL": self.B_LOC[:, PLANE_QL], "TENDENCY_LOC_QI": self.B_LOC[:, PLANE_QI],
+        }
+
+
+def state_from_table(tab: dict, nproma: int, ngptot: int, col0: int = 0, poison_outputs: float | None = None) -> Cloudsc2State:
+    """LOAD of cloudsc2_array_state_mod.F90:153-203 with the table standing in for input.h5: tile the inputs
+    (LOAD_AND_EXPAND, :167-182) and zero-initialise the outputs (FIELD_INIT, :186-190)."""
+    nlev = tab["PT"].shape[0]
+    nb = nblocks_of(ngptot, nproma)
+    t = lambda name: _tile(tab[name], nproma, ngptot, col0)  # noqa: E731
+    b_cml = np.zeros((nb, 8, nlev, nproma))
+    b_cml[:, PLANE_T] = t("TENDENCY_CML_T")
+    b_cml[:, PLANE_Q] = t("TENDENCY_CML_Q")
+    b_cml[:, PLANE_QL] = t("TENDENCY_CML_QL")
+    b_cml[:, PLANE_QI] = t("TENDENCY_CML_QI")
+    pclv = np.zeros((nb, 5, nlev, nproma))
+    pclv[:, NCLDQL] = t("PCLV_QL")
+    pclv[:, NCLDQI] = t("PCLV_QI")
+    fill = 0.0 if poison_outputs is None else poison_outputs
+    full = lambda: np.full((nb, nlev, nproma), fill)  # noqa: E731
+    half = lambda: np.full((nb, nlev + 1, nproma), fill)  # noqa: E731
+    return Cloudsc2State(
+        nproma=nproma, nlev=nlev, ngptot=ngptot, ptsphy=float(tab["PTSPHY"]),
+        PT=t("PT"), PQ=t("PQ"), B_CML=b_cml, B_LOC=np.full((nb, 8, nlev, nproma), fill),
+        PAP=t("PAP"), PAPH=t("PAPH"), PLU=t("PLU"), PLUDE=t("PLUDE"), PMFU=t("PMFU"), PMFD=t("PMFD"),
+        PA=t("PA") if poison_outputs is None else full(), PCLV=pclv, PSUPSAT=t("PSUPSAT"),
+        PCOVPTOT=full(), PFPLSL=half(), PFPLSN=half(), PFHPSL=half(), PFHPSN=half(),
+    )
+
+
+def bytes_per_column(nlev: int, kernel: str = "nl") -> int:
+    """Algorithmic HBM bytes per column: every input plane read once, every output plane written once."""
+    full, half = nlev, nlev + 1
+    nl_in = half + 14 * full                 # PAPH + 14 full-level planes (PQS comes from the fused SATUR)
+    nl_out = 6 * full + 4 * half             # PTEN{T,Q,L,I}, PCLC, PCOVPTOT + 4 flux planes
+    if kernel == "nl":
+        return 8 * (nl_in + nl_out)
+    if kernel == "nl_driver":                # + the driver's CLD(:,:,NCLV)=0 plane
+        return 8 * (nl_in + nl_out + full)
+    if kernel == "tl":
+        return 8 * (nl_in + full + (half + 15 * full) + 2 * nl_out)
+    if kernel == "ad":
+        x = half + 15 * full
+        return 8 * ((nl_in + full) + nl_out + x + nl_out + x + nl_out)
+    raise ValueError(kernel)
+
+
+def validate_l1(ref: np.ndarray, got: np.ndarray) -> float:
+    """The reference's acceptance number per field: sum|err| / sum|ref| (validate_mod.F90:274-289); a field is flagged
+    when it exceeds 10*eps."""
+    den = float(np.sum(np.abs(ref)))
+    num = float(np.sum(np.abs(got - ref)))
+    if den == 0.0:
+        return 0.0 if num == 0.0 else math.inf
+    return num / den

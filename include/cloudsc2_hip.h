@@ -1,0 +1,180 @@
+/*
+ * cloudsc2_hip.h -- C ABI of the MI355X-native CLOUDSC2 NL / TL / AD column-physics engine.
+ *
+ * This is the drop-in boundary for the hot path of ecmwf-ifs/dwarf-p-cloudsc2-tl-ad.  The reference has
+ * no FFI layer; its de-facto boundary is the three driver procedures and the F77-style kernels they call
+ * (SURVEY.md 8b).  Every entry point below cites the reference interface it replaces (paths relative to
+ * the reference checkout).  All arrays are fp64 (JPRB, src/common/module/parkind1.F90:43) in the
+ * reference's NPROMA-blocked layout, column index fastest:
+ *
+ *     field(NPROMA, NLEV or NLEV+1, NBLOCKS)         f[jl + NPROMA*(jk + NLEVx*ibl)]
+ *     B_CML / B_LOC (NPROMA, NLEV, 8, NBLOCKS)       planes T=0, A=1, Q=2, CLD(QL,QI,QR,QS,QV)=3..7
+ *                                                    (src/common/module/cloudsc2_array_state_mod.F90:129-151)
+ *     PCLV (NPROMA, NLEV, 5, NBLOCKS)                planes QL=0, QI=1 used (yoecldp.F90:86-91)
+ *
+ * No torch types, no C++ types: plain pointers and sizes.  Return value 0 = OK, otherwise a negative
+ * CLOUDSC2_E* code or a positive hipError_t; cloudsc2_last_error() gives the text.  The library has NO CPU
+ * fallback: without a HIP device every launch/run entry point fails with CLOUDSC2_ENODEVICE.
+ */
+#ifndef CLOUDSC2_HIP_H
+#define CLOUDSC2_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLOUDSC2_MAX_NLEV 200 /* the reference's own limit, src/cloudsc2_nl/dwarf_cloudsc.F90:87 */
+
+#define CLOUDSC2_EINVAL    (-1)
+#define CLOUDSC2_ENODEVICE (-2)
+#define CLOUDSC2_ETLWRONG  (-3) /* "TL is totally wrong" STOP of cloudsc_driver_tl_mod.F90:247-249 */
+
+/* Constants and switches the reference keeps in modules and loads from input.h5:
+ * YOMCST (yomcst.F90:167-177), YOETHF (yoethf.F90:79-99), YOECLDP (yoecldp.F90:247-250,...),
+ * YOEPHLI (yoephli.F90:79-97), YOECLD%CETA (dwarf_cloudsc.F90:100-102), YRPHNC%LEVAPLS2 (:105),
+ * YRNCL%LREGCL (src/cloudsc2_tl/dwarf_cloudsc.F90:105), LDRAIN1D (cloudsc_driver_mod.F90:61).
+ * The first 30 doubles are also the order oracle/ref_harness.F90 takes them in. */
+typedef struct cloudsc2_params {
+  double rg, rd, rcpd, retv, rlvtt, rlstt, rlmlt, rtt;                         /* YOMCST  */
+  double r2es, r3les, r3ies, r4les, r4ies, r5les, r5ies, r5alvcp, r5alscp,     /* YOETHF  */
+         ralvdcp, ralsdcp, rtwat, rtice, rtwat_rtice_r, rvtmp2;
+  double rclcrit, rkconv, rlmin, rpecons;                                      /* YOECLDP */
+  double rlptrc;                                                               /* YOEPHLI */
+  double rticecu, rtwat_rticecu_r;                                             /* YOETHF, dead branches only */
+  int lphylin;   /* must be 1: every reference main forces it (dwarf_cloudsc.F90:107) */
+  int levapls2;  /* precipitation evaporation on/off (LEVAPLS2 .OR. LDRAIN1D, cloudsc2.F90:557) */
+  int lregcl;    /* TL/AD regularisation (cloudsc2tl.F90:575,657,754,794,998) */
+  int ldrain1d;
+  int nlev;
+  int reserved;
+  double ceta[CLOUDSC2_MAX_NLEV];
+} cloudsc2_params;
+
+/* Fill *p with the standard IFS constants and the reference mains' switches; nlev and ceta
+ * are left for the caller (ceta(jk) = PAP(1,jk,1)/PAPH(1,nlev+1,1), dwarf_cloudsc.F90:100-102). */
+void cloudsc2_params_default(cloudsc2_params* p);
+
+const char* cloudsc2_last_error(void);
+/* 1 if a HIP device is usable by this process, else 0. */
+int cloudsc2_device_available(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Kernel level: DEVICE pointers, asynchronous on `stream` (a hipStream_t, NULL = default stream).
+ * One field = base pointer + stride between NPROMA blocks (in doubles); level stride is NPROMA,
+ * column stride 1.  A (NPROMA,NLEV,NBLOCKS) array has block_stride NPROMA*NLEV; plane p of B_CML has
+ * ptr = b_cml + p*NPROMA*NLEV and block_stride 8*NPROMA*NLEV.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct cloudsc2_field {
+  double* ptr;
+  long long block_stride;
+} cloudsc2_field;
+
+/* The 16 inputs of CLOUDSC2 in the dummy-argument order of src/cloudsc2_nl/cloudsc2.F90:13-16:
+ * PAPHP1(NLEV+1) PAPP1 PQM1 PQS PTM1 PL PI PLUDE PLU PMFU PMFD PGTENT PGTENQ PGTENL PGTENI PSUPSAT. */
+typedef struct cloudsc2_inputs {
+  cloudsc2_field paph, pap, q, qsat, t, l, i, lude, lu, mfu, mfd, gtent, gtenq, gtenl, gteni, supsat;
+} cloudsc2_inputs;
+
+/* The 10 outputs (cloudsc2.F90:15-18): PTENT PTENQ PTENL PTENI PCLC PFPLSL PFPLSN PFHPSL PFHPSN
+ * (fluxes NLEV+1) PCOVPTOT. */
+typedef struct cloudsc2_outputs {
+  cloudsc2_field tent, tenq, tenl, teni, clc, fplsl, fplsn, fhpsl, fhpsn, covptot;
+} cloudsc2_outputs;
+
+/* SATUR + CLOUDSC2 for all blocks: replaces the body of the block loop of
+ * src/cloudsc2_nl/cloudsc_driver_mod.F90:82-111 (SATUR call :91, CLOUDSC2 call :94-107).
+ * in->qsat.ptr == NULL  => PQS is computed in-kernel from PAP,PT (SATUR fused, satur.F90:106-123);
+ * in->qsat.ptr != NULL  => PQS is read (the TL/AD test drivers perturb it independently).
+ * zero_plane (optional, may have ptr NULL): an extra (NPROMA,NLEV) plane per block that is zero-filled,
+ * i.e. TENDENCY_LOC(IBL)%cld(:,:,NCLV)=0 of cloudsc_driver_mod.F90:88.
+ * pert_lambda != 0: every input x is replaced on load by x + pert_lambda*(0.01*x), the perturbed state
+ * of the Taylor test (cloudsc_driver_tl_mod.F90:156-171,200-215); with fused SATUR, PQS is perturbed the
+ * same way after SATUR on the unperturbed PAP,PT (:159,:203). */
+int cloudsc2_nl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
+                       const cloudsc2_inputs* in, const cloudsc2_outputs* out, cloudsc2_field zero_plane,
+                       double pert_lambda, void* stream);
+
+/* SATUR only (satur.F90:106-123, LDPHYLIN branch): qsat(NPROMA,NLEV,NBLOCKS) from pap, t. */
+int cloudsc2_satur_launch(const cloudsc2_params* prm, int nproma, int nlev, int ngptot,
+                          cloudsc2_field pap, cloudsc2_field t, cloudsc2_field qsat, void* stream);
+
+/* CLOUDSC2TL (src/cloudsc2_tl/cloudsc2tl.F90:10-24): trajectory in -> trajectory out (traj_out fields
+ * may have ptr NULL to skip the store), perturbation in -> perturbation out.  traj_in->qsat NULL => fused
+ * SATUR for PQS5.  pert_in must give all 16 fields. */
+int cloudsc2_tl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
+                       const cloudsc2_inputs* traj_in, const cloudsc2_outputs* traj_out,
+                       const cloudsc2_inputs* pert_in, const cloudsc2_outputs* pert_out, void* stream);
+
+/* CLOUDSC2AD (src/cloudsc2_ad/cloudsc2ad.F90:10-24): trajectory in -> trajectory out; adj_out holds the
+ * output adjoints on entry and is zeroed on return (:917-919,955-966,1173,1572,1678-1691); adj_in is
+ * accumulated (+=, :1723-1738) except PSUPSAT which is assigned PTSPHY*zqp1 exactly as the reference does
+ * (:1733).  `scratch` must hold (ngptot rounded up to NPROMA blocks) * nlev doubles (precipitation-cover
+ * carry checkpoints). */
+int cloudsc2_ad_launch(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
+                       const cloudsc2_inputs* traj_in, const cloudsc2_outputs* traj_out,
+                       const cloudsc2_inputs* adj_in, const cloudsc2_outputs* adj_out,
+                       double* scratch, void* stream);
+
+/* Taylor-test statistics for one lambda (ERROR_NORM, cloudsc_driver_tl_mod.F90:21-31, calls :233-244):
+ * for each NPROMA block and each of the 10 output fields, sums over the block's active columns and all
+ * levels of (F(x)-F(x+lambda dx)) and of (TL dx * lambda).  sums(NBLOCKS,10,2) device doubles. */
+int cloudsc2_taylor_sums_launch(int nproma, int nlev, int ngptot, const cloudsc2_outputs* f,
+                                const cloudsc2_outputs* f_pert, const cloudsc2_outputs* tl, double lambda,
+                                double* sums, void* stream);
+
+/* Adjoint-test norms per column (cloudsc_driver_ad_mod.F90:184-195,240-264):
+ * norm1 = sum_lev sum_10 y*y, norm2 = sum_lev sum_16 (0.01*x_traj)*x_adj (PSUPSAT term uses x0=0, :139),
+ * norm3 = |n1-n2|/eps [/n2].  norms(3, ncols_padded) device doubles; *blockmax (device double) receives
+ * max(norm3) over all columns via atomic max (must be zeroed by the caller). */
+int cloudsc2_adjoint_norms_launch(int nproma, int nlev, int ngptot, const cloudsc2_inputs* traj_in,
+                                  const cloudsc2_field* qsat, const cloudsc2_outputs* y,
+                                  const cloudsc2_inputs* x_adj, double* norms, double* blockmax, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Driver level: HOST pointers in the GLOBAL_STATE layout, synchronous.  These are what the Fortran
+ * drivers with the reference signatures bind through ISO_C_BINDING.  Device buffers
+ * are owned by the library and cached between calls (cloudsc2_release_workspace frees them).
+ * Argument order follows CLOUDSC_DRIVER (src/cloudsc2_nl/cloudsc_driver_mod.F90:22-30):
+ *   PT PQ TENDENCY_CML TENDENCY_LOC PAP PAPH PLU PLUDE PMFU PMFD PA PCLV PSUPSAT PCOVPTOT PFPLSL PFPLSN
+ *   PFHPSL PFHPSN, with TENDENCY_* passed as the base address of B_CML / B_LOC.
+ * kernel_ms (optional): device time of the kernels only (hipEvent), excluding H2D/D2H.
+ * ------------------------------------------------------------------------------------------------ */
+int cloudsc2_nl_run(const cloudsc2_params* prm, int nproma, int nlev, int ngptot, double ptsphy,
+                    const double* pt, const double* pq, const double* b_cml, double* b_loc,
+                    const double* pap, const double* paph, const double* plu, const double* plude,
+                    const double* pmfu, const double* pmfd, double* pa, const double* pclv,
+                    const double* psupsat, double* pcovptot, double* pfplsl, double* pfplsn,
+                    double* pfhpsl, double* pfhpsn, double* kernel_ms);
+
+/* CLOUDSC_DRIVER_TL (src/cloudsc2_tl/cloudsc_driver_tl_mod.F90:33-314): NL, 1 % increments, TL, ten
+ * perturbed NL runs, ERROR_NORM per block, max over blocks.  znormg[10] receives the raw ratios
+ * (the values printed at :275).  Returns CLOUDSC2_ETLWRONG where the reference STOPs (:247-249). */
+int cloudsc2_tl_taylor_run(const cloudsc2_params* prm, int nproma, int nlev, int ngptot, double ptsphy,
+                           const double* pt, const double* pq, const double* b_cml, double* b_loc,
+                           const double* pap, const double* paph, const double* plu, const double* plude,
+                           const double* pmfu, const double* pmfd, double* pa, const double* pclv,
+                           const double* psupsat, double* pcovptot, double* pfplsl, double* pfplsn,
+                           double* pfhpsl, double* pfhpsn, double znormg[10], double* kernel_ms);
+
+/* CLOUDSC_DRIVER_AD (src/cloudsc2_ad/cloudsc_driver_ad_mod.F90:22-297): TL, norm1, zero, AD, norm2,
+ * norm3; *znormg = max over columns of norm3 (the value printed at :287). */
+int cloudsc2_ad_symmetry_run(const cloudsc2_params* prm, int nproma, int nlev, int ngptot, double ptsphy,
+                             const double* pt, const double* pq, const double* b_cml, double* b_loc,
+                             const double* pap, const double* paph, const double* plu, const double* plude,
+                             const double* pmfu, const double* pmfd, double* pa, const double* pclv,
+                             const double* psupsat, double* pcovptot, double* pfplsl, double* pfplsn,
+                             double* pfhpsl, double* pfhpsn, double* znormg, double* kernel_ms);
+
+void cloudsc2_release_workspace(void);
+
+/* Verdict logic of the two self-tests, pure host code (no device needed).
+ * cloudsc2_taylor_verdict: cloudsc_driver_tl_mod.F90:272-311; znormg = raw ratios; returns 1 = PASSED;
+ *   *itest = penalty / error code (13 when no lambda <= 1e-4 reaches |1-ratio| < 0.5).
+ * cloudsc2_adjoint_verdict: cloudsc_driver_ad_mod.F90:289; returns 1 = TEST OK. */
+int cloudsc2_taylor_verdict(const double znormg[10], int* itest);
+int cloudsc2_adjoint_verdict(double znormg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLOUDSC2_HIP_H */

@@ -1,0 +1,138 @@
+// TEST-ONLY: compiles the per-column device functions of csrc/cloudsc2_column.hpp for the HOST (hipcc
+// --cuda-host-only) so that their logic can be unit-tested against the oracle in a container without a GPU.
+// This library is never loaded by the package, the bench or the C ABI; the product has no CPU path.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+
+#include "../../include/cloudsc2_hip.h"
+#include "../../dwarf_p_cloudsc2_tl_ad_amd/csrc/cloudsc2_column.hpp"
+
+using namespace cloudsc2;
+
+// same derivation as make_consts()/get_tables() in cloudsc2_kernels.hip
+static Consts hc_consts(const cloudsc2_params& p, double ptsphy) {
+  Consts c;
+  c.rg = p.rg; c.rd = p.rd; c.rcpd = p.rcpd; c.retv = p.retv; c.rlvtt = p.rlvtt; c.rlstt = p.rlstt;
+  c.rlmlt = p.rlmlt; c.rtt = p.rtt;
+  c.r2es = p.r2es; c.r3les = p.r3les; c.r3ies = p.r3ies; c.r4les = p.r4les; c.r4ies = p.r4ies;
+  c.r5les = p.r5les; c.r5ies = p.r5ies; c.r5alvcp = p.r5alvcp; c.r5alscp = p.r5alscp;
+  c.ralvdcp = p.ralvdcp; c.ralsdcp = p.ralsdcp;
+  c.rtwat = p.rtwat; c.rtice = p.rtice; c.rtwat_rtice_r = p.rtwat_rtice_r; c.rvtmp2 = p.rvtmp2;
+  c.rlmin = p.rlmin; c.rpecons = p.rpecons; c.rlptrc = p.rlptrc;
+  c.ptsphy = ptsphy;
+  c.zckcodtl = 2.0 * p.rkconv * ptsphy;
+  c.zckcodti = 5.0 * p.rkconv * ptsphy;
+  c.zckcodtla = c.zckcodtl / 100.0;
+  c.zckcodtia = c.zckcodti / 100.0;
+  c.zcons2 = 1.0 / (ptsphy * p.rg);
+  c.zcons3 = p.rlvtt / p.rcpd;
+  c.zmeltp2 = p.rtt + 2.0;
+  c.zqtmst = 1.0 / ptsphy;
+  c.evap = (p.levapls2 || p.ldrain1d) ? 1 : 0;
+  c.zlcrit_l = c.evap ? 1.9 * p.rclcrit : p.rclcrit * 2.0;
+  c.zlcrit_i = c.evap ? 1.e-04 : p.rclcrit * 2.0;
+  c.rcpd_r = 1.0 / p.rcpd;
+  c.rvtmp2_zero = (p.rvtmp2 == 0.0) ? 1 : 0;
+  c.zzz0 = 1.0 / (p.rcpd + p.rcpd * p.rvtmp2 * 0.0);
+  c.lregcl = p.lregcl ? 1 : 0;
+  c.nlev = p.nlev;
+  return c;
+}
+
+static void hc_tables(const cloudsc2_params& p, LevelTab& tab, Geom& g) {
+  memset(&tab, 0, sizeof(tab));
+  g.kb0 = p.nlev; g.kb1 = 0;
+  for (int jk = 0; jk < p.nlev; ++jk) {
+    tab.ceta[jk] = p.ceta[jk];
+    tab.zscalm[jk] = 0.9 * pow(fmax(p.ceta[jk] - 0.2, 1.e-12), 0.2);
+    if (jk < p.nlev - 1 && p.ceta[jk] > 0.1 && p.ceta[jk] < 0.4) {
+      if (jk < g.kb0) g.kb0 = jk;
+      if (jk + 1 > g.kb1) g.kb1 = jk + 1;
+    }
+  }
+  if (g.kb1 <= g.kb0) { g.kb0 = 0; g.kb1 = 0; }
+}
+
+static void hc_in(const cloudsc2_inputs& in, Strides& s, InPtrs& p) {
+  s.full = in.pap.block_stride; s.half = in.paph.block_stride; s.cml = in.gtent.block_stride; s.clv = in.l.block_stride;
+  p.paph = in.paph.ptr; p.pap = in.pap.ptr; p.q = in.q.ptr; p.qsat = in.qsat.ptr; p.t = in.t.ptr; p.l = in.l.ptr;
+  p.i = in.i.ptr; p.lude = in.lude.ptr; p.lu = in.lu.ptr; p.mfu = in.mfu.ptr; p.mfd = in.mfd.ptr;
+  p.gt = in.gtent.ptr; p.gq = in.gtenq.ptr; p.gl = in.gtenl.ptr; p.gi = in.gteni.ptr; p.supsat = in.supsat.ptr;
+}
+static void hc_out(const cloudsc2_outputs& out, Strides& s, OutPtrs& p) {
+  s.loc = out.tent.block_stride;
+  p.tent = out.tent.ptr; p.tenq = out.tenq.ptr; p.tenl = out.tenl.ptr; p.teni = out.teni.ptr; p.clc = out.clc.ptr;
+  p.fplsl = out.fplsl.ptr; p.fplsn = out.fplsn.ptr; p.fhpsl = out.fhpsl.ptr; p.fhpsn = out.fhpsn.ptr;
+  p.covptot = out.covptot.ptr;
+}
+
+static Geom hc_geom(int nproma, int nlev, int ngptot) {
+  Geom g;
+  long long nb = ((long long)ngptot + nproma - 1) / nproma;
+  g.nproma = nproma; g.nlev = nlev; g.ngptot = ngptot; g.ncols_pad = nb * nproma; g.kb0 = g.kb1 = 0;
+  return g;
+}
+
+extern "C" {
+
+int hostcheck_satur(const cloudsc2_params* prm, int nproma, int nlev, int ngptot, cloudsc2_field pap, cloudsc2_field t,
+                    cloudsc2_field qsat) {
+  Geom g = hc_geom(nproma, nlev, ngptot);
+  Consts c = hc_consts(*prm, 1.0);
+  Strides s = {pap.block_stride, 0, 0, 0, 0};
+  for (long long gc = 0; gc < g.ncols_pad; ++gc) satur_column(gc, c, g, s, pap.ptr, t.ptr, qsat.ptr);
+  return 0;
+}
+
+int hostcheck_nl(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot, const cloudsc2_inputs* in,
+                 const cloudsc2_outputs* out, cloudsc2_field zero_plane, double lam) {
+  Geom g = hc_geom(nproma, nlev, ngptot);
+  Consts c = hc_consts(*prm, ptsphy);
+  LevelTab tab; hc_tables(*prm, tab, g);
+  Strides s = {0, 0, 0, 0, 0}; InPtrs ip; OutPtrs op;
+  hc_in(*in, s, ip); hc_out(*out, s, op);
+  const bool hq = in->qsat.ptr != nullptr, pt = lam != 0.0;
+  for (long long gc = 0; gc < g.ncols_pad; ++gc) {
+    if (hq && pt) nl_column<true, true>(gc, c, &tab, g, s, ip, op, zero_plane.ptr, zero_plane.block_stride, lam);
+    else if (hq) nl_column<true, false>(gc, c, &tab, g, s, ip, op, zero_plane.ptr, zero_plane.block_stride, lam);
+    else if (pt) nl_column<false, true>(gc, c, &tab, g, s, ip, op, zero_plane.ptr, zero_plane.block_stride, lam);
+    else nl_column<false, false>(gc, c, &tab, g, s, ip, op, zero_plane.ptr, zero_plane.block_stride, lam);
+  }
+  return 0;
+}
+
+int hostcheck_tl(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot, const cloudsc2_inputs* in,
+                 const cloudsc2_outputs* out, const cloudsc2_inputs* din, const cloudsc2_outputs* dout) {
+  Geom g = hc_geom(nproma, nlev, ngptot);
+  Consts c = hc_consts(*prm, ptsphy);
+  LevelTab tab; hc_tables(*prm, tab, g);
+  Strides s = {0, 0, 0, 0, 0}, sp = {0, 0, 0, 0, 0}; InPtrs ip, dip; OutPtrs op, dop;
+  hc_in(*in, s, ip); hc_out(*out, s, op); hc_in(*din, sp, dip); hc_out(*dout, sp, dop);
+  for (long long gc = 0; gc < g.ncols_pad; ++gc) {
+    if (in->qsat.ptr) tl_column<true>(gc, c, &tab, g, s, sp, ip, op, dip, dop);
+    else tl_column<false>(gc, c, &tab, g, s, sp, ip, op, dip, dop);
+  }
+  return 0;
+}
+
+int hostcheck_ad(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot, const cloudsc2_inputs* in,
+                 const cloudsc2_outputs* out, const cloudsc2_inputs* ain, const cloudsc2_outputs* aout, double* scratch) {
+  Geom g = hc_geom(nproma, nlev, ngptot);
+  Consts c = hc_consts(*prm, ptsphy);
+  LevelTab tab; hc_tables(*prm, tab, g);
+  Strides s = {0, 0, 0, 0, 0}, sa = {0, 0, 0, 0, 0}; InPtrs ip, aip_c; OutPtrs op, aop;
+  hc_in(*in, s, ip); hc_out(*out, s, op); hc_in(*ain, sa, aip_c); hc_out(*aout, sa, aop);
+  InPtrsRW aip;
+  aip.paph = ain->paph.ptr; aip.pap = ain->pap.ptr; aip.q = ain->q.ptr; aip.qsat = ain->qsat.ptr; aip.t = ain->t.ptr;
+  aip.l = ain->l.ptr; aip.i = ain->i.ptr; aip.lude = ain->lude.ptr; aip.lu = ain->lu.ptr; aip.mfu = ain->mfu.ptr;
+  aip.mfd = ain->mfd.ptr; aip.gt = ain->gtent.ptr; aip.gq = ain->gtenq.ptr; aip.gl = ain->gtenl.ptr; aip.gi = ain->gteni.ptr;
+  aip.supsat = ain->supsat.ptr;
+  for (long long gc = 0; gc < g.ncols_pad; ++gc) {
+    if (in->qsat.ptr) ad_column<true>(gc, c, &tab, g, s, sa, ip, op, aip, aop, scratch);
+    else ad_column<false>(gc, c, &tab, g, s, sa, ip, op, aip, aop, scratch);
+  }
+  return 0;
+}
+
+}  // extern "C"
