@@ -1,0 +1,189 @@
+#!/usr/bin/env python
+"""bench.py -- CLOUDSC2 NL hot path (SATUR + CLOUDSC2 over all NPROMA blocks) on N MI355X GPUs.
+
+One "step" = one pass of the NL kernel over this rank's NGPTOT=160000 columns x 137 levels (fp64), inputs resident
+in HBM.  Weak scaling: every rank owns its own 160000-column sub-range of the global columns (the reference's MPI
+split); there is no collective in the data path.  Prints ONE JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def effective_cores() -> int:
+    """CPU share of this process: cgroup quota if one is set, else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / p + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return int(os.environ.get("CLOUDSC2_CPU_THREADS", n))
+
+
+def cpu_baseline(tab, prm, nproma, ngptot, budget_s=20.0):
+    """The checker timed on the host cores (reported baseline, not the target).  kind "reference" = the unmodified
+    reference driver+kernels (oracle/_ref), else the C port.  Same workload, bounded to ~budget_s of CPU work."""
+    import dwarf_p_cloudsc2_tl_ad_amd as c2
+    from oracle import refcall
+
+    cores = effective_cores()
+    st = c2.state_from_table(tab, nproma, ngptot)
+    if refcall.have_ref():
+        lib, kind = refcall.RefLib(), "reference"
+        lib.set_params(prm.doubles30(), prm.ceta_array())
+        os.environ.setdefault("OMP_SCHEDULE", "static")
+        arrays = st.driver_arrays()
+        run = lambda: lib.driver(0, cores, nproma, st.nlev, ngptot, st.ptsphy, arrays)  # noqa: E731
+    elif refcall.have_oracle():
+        lib, kind = refcall.OracleLib(), "port"
+        lib.set_params(prm.doubles30(), prm.ceta_array())
+        import ctypes as C
+
+        dp = C.POINTER(C.c_double)
+        lib.lib.oracle_driver_nl.argtypes = [C.c_int] * 4 + [C.c_double] + [dp] * 18
+        ptrs = [a.ctypes.data_as(dp) for a in st.driver_arrays()]
+        run = lambda: lib.lib.oracle_driver_nl(cores, nproma, st.nlev, ngptot, st.ptsphy, *ptrs)  # noqa: E731
+    else:
+        return None
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    saved = os.dup(2)
+    os.dup2(devnull, 2)  # the reference driver prints its timing table on stderr
+    try:
+        run()  # warm-up (page faults)
+        times = []
+        t_end = time.perf_counter() + budget_s
+        while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 20):
+            t0 = time.perf_counter()
+            run()
+            times.append(time.perf_counter() - t0)
+    finally:
+        os.dup2(saved, 2)
+        os.close(devnull)
+        os.close(saved)
+    best = float(np.median(times))
+    return {"value": ngptot / best, "unit": "columns/s", "cores": cores, "kind": kind,
+            "sample": f"NL, {ngptot} columns x 137 levels, NPROMA {nproma}, median of {len(times)} full passes "
+                      f"({best * 1e3:.0f} ms each), OMP_SCHEDULE=static"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--ngptot", type=int, default=160000, help="columns per GPU")
+    ap.add_argument("--nproma", type=int, default=128)
+    ap.add_argument("--kernel", choices=["nl", "tl", "ad"], default="nl")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    import dwarf_p_cloudsc2_tl_ad_amd as c2
+    from dwarf_p_cloudsc2_tl_ad_amd import dist as c2dist
+
+    rank, local, world = c2dist.init_process_group()
+    if not torch.cuda.is_available() or not c2.device_available():
+        raise SystemExit("bench.py needs a HIP device: the CLOUDSC2 engine has no CPU path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    tab = c2.synthetic_table()
+    prm = c2.default_params(c2.ceta_from_table(tab), lregcl=(args.kernel == "ad"))
+    col0 = rank * args.ngptot  # weak scaling: rank r owns global columns [r*NGPTOT, (r+1)*NGPTOT)
+    st = c2.state_from_table(tab, args.nproma, args.ngptot, col0=col0)
+    ds = c2.DeviceState(st, dev)
+    stream = torch.cuda.current_stream(dev)
+
+    if args.kernel == "nl":
+        step = lambda: ds.nl(prm, stream)  # noqa: E731
+        bpc = c2.bytes_per_column(st.nlev, "nl_driver")
+        kname = "nl_kernel<false,false> (SATUR + CLOUDSC2)"
+    else:
+        ds.satur(prm, stream)
+        inc = ds.increments(zero_supsat=(args.kernel == "ad"))
+        dout = c2.FlatFields("out", ds.nb, ds.nlev, ds.nproma, dev)
+        if args.kernel == "tl":
+            step = lambda: ds.tl(prm, inc, dout, stream)  # noqa: E731
+            bpc = c2.bytes_per_column(st.nlev, "tl")
+            kname = "tl_kernel<true> (CLOUDSC2TL)"
+        else:
+            ds.tl(prm, inc, dout, stream)
+            scratch = ds.new_scratch()
+            step = lambda: ds.ad(prm, inc, dout, scratch, stream)  # noqa: E731
+            bpc = c2.bytes_per_column(st.nlev, "ad") + 2 * 8 * st.nlev  # + carry checkpoint plane (write + read)
+            kname = "ad_kernel<true> (CLOUDSC2AD)"
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        torch.distributed.barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record(stream)
+        step()
+        b.record(stream)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kms = np.array([a.elapsed_time(b) for a, b in ev])  # per-launch device time on the launch stream
+    ms_per_step = elapsed / args.steps * 1e3
+    total_cols = args.ngptot * world
+    value = total_cols / (elapsed / args.steps)
+
+    k_avg = float(kms.mean())
+    achieved = bpc * args.ngptot / (k_avg * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_column": bpc,
+                "kernel_ms_avg": k_avg, "kernel_ms_min": float(kms.min())}
+
+    out = {
+        "metric": f"CLOUDSC2 {args.kernel.upper()} columns/sec (fp64, NLEV=137)", "value": value, "unit": "columns/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"CLOUDSC2 {args.kernel.upper()} fp64, NGPTOT={args.ngptot} columns per GPU, NLEV=137, "
+                               f"NPROMA={args.nproma} (BASELINE.json configs[1])",
+                   "ngptot_per_gpu": args.ngptot, "nlev": st.nlev, "nproma": args.nproma,
+                   "parallelism": f"columns sharded over {world} GPU(s), no data-path collective"},
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.kernel == "nl":
+        cb = cpu_baseline(tab, prm, 32, args.ngptot)
+        if cb:
+            out["cpu_baseline"] = cb
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

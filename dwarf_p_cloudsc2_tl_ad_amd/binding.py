@@ -80,6 +80,13 @@ def _load() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} not found: the HIP library has not been built (run `python -c 'import __graft_entry__ as g; "
             "g.build()'` or `make -C dwarf_p_cloudsc2_tl_ad_amd/csrc`). There is no CPU fallback.")
+    # One HIP/HSA runtime per process: the torch wheel bundles its own libamdhip64.so.7 / libhsa-runtime64 and a second
+    # copy (the system ROCm one this library was linked against) cannot open the GPU any more.  Loading torch first
+    # makes the dynamic loader resolve this library's NEEDED libamdhip64.so.7 to the copy that is already mapped.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     dp = C.POINTER(C.c_double)
     pp = C.POINTER(Params)

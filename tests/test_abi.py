@@ -1,0 +1,79 @@
+"""The C-ABI library loads, exports every symbol include/cloudsc2_hip.h declares, and its host-only entry points
+behave like the reference (no compute calls here: there is no GPU in this container)."""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tests.util import ROOT, B, c2
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "cloudsc2_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(cloudsc2_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_every_declared_symbol_is_exported():
+    syms = declared_symbols()
+    assert set(syms) == set(B.EXPORTED)
+    for s in syms:
+        assert hasattr(B.lib, s), s
+
+
+def test_params_struct_layout_and_defaults():
+    assert C.sizeof(B.Params) == 30 * 8 + 6 * 4 + 200 * 8
+    p = c2.default_params()
+    # the derived YOETHF constants
+    assert p.r5les == p.r3les * (p.rtt - p.r4les) and p.r5alvcp == p.r5les * p.rlvtt / p.rcpd
+    assert p.rlmlt == p.rlstt - p.rlvtt and p.rvtmp2 == 0.0 and p.lphylin == 1
+    assert abs(p.rlptrc - 266.42345) < 1e-4
+    assert p.rlstt == 2834500.0  # confirmed by config-files/reference.h5 (tests/test_oracle.py)
+
+
+def test_verdicts_follow_the_reference_drivers():
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "drivers.json")))["drivers"]
+    for key, want_pen in (("tl_nproma32_ngptot100", 0), ("tl_nproma1_ngptot100", 5)):
+        ok, itest = c2.taylor_verdict(gold[key]["znormg"])
+        assert ok and itest == want_pen
+        assert gold[key]["verdict"].startswith("TEST PASSED") and gold[key]["verdict"].endswith(str(want_pen))
+    # no lambda <= 1e-4 gets within 0.5: err 13 (cloudsc_driver_tl_mod.F90:285-286)
+    assert c2.taylor_verdict([3.0] * 4 + [1.0] * 6) == (False, 13)
+    # monotone convergence without the V turn: ITEST = 11 (:300)
+    assert c2.taylor_verdict([1.0 + 10.0 ** (-k) for k in range(1, 11)])[1] in (11, 11 + 0)
+    assert c2.adjoint_verdict(9999.0) and not c2.adjoint_verdict(10000.0)
+
+
+def test_compute_entry_points_fail_loudly_without_a_gpu():
+    if c2.device_available():
+        pytest.skip("a GPU is present")
+    tab = c2.synthetic_table()
+    prm = c2.default_params(c2.ceta_from_table(tab))
+    st = c2.state_from_table(tab, 32, 64)
+    for which in ("nl", "tl", "ad"):
+        with pytest.raises(c2.Cloudsc2Error) as e:
+            c2.run_state(prm, st, which)
+        assert e.value.code == B.CLOUDSC2_ENODEVICE
+        assert "no CPU path" in str(e.value)
+
+
+def test_state_layout_and_tiling():
+    tab = c2.synthetic_table()
+    st = c2.state_from_table(tab, 32, 250)
+    assert st.nblocks == 8 and st.PT.shape == (8, 137, 32) and st.PAPH.shape == (8, 138, 32)
+    cols = st.PT.transpose(0, 2, 1).reshape(-1, 137)
+    assert np.array_equal(cols[:250], tab["PT"].T[np.arange(250) % 100])  # periodic tiling, expand_mod.F90:283-296
+    assert not cols[250:].any()                                           # zero-padded tail (:299)
+    assert np.array_equal(st.B_CML[:, 2].transpose(0, 2, 1).reshape(-1, 137)[:100], tab["TENDENCY_CML_Q"].T)
+    # a rank's sub-range continues the same periodic sequence (dwarf_cloudsc.F90:66-69)
+    a, b = c2.column_range(250, 1, 2)
+    assert (a, b) == (125, 250)
+    st1 = c2.state_from_table(tab, 32, b - a, col0=a)
+    assert np.array_equal(st1.PT.transpose(0, 2, 1).reshape(-1, 137)[: b - a], cols[a:b])
+    assert c2.bytes_per_column(137, "nl") == 27440 and c2.bytes_per_column(137, "tl") == 57072
+    assert c2.bytes_per_column(137, "ad") == 85608

@@ -1,0 +1,134 @@
+"""The per-column device functions (csrc/cloudsc2_level.hpp + cloudsc2_column.hpp) compiled for the HOST and run
+against the oracle -- exercises exactly the code the HIP kernels wrap (level physics, lane indexing, prefetch
+double-buffer, checkpoint/recompute adjoint sweep) in a container without a GPU.  The host build is a unit-test
+vehicle only; the real parity tests are tests/test_gpu_parity.py through the C ABI on the MI355X.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.util import (B, c2, flat_block, flat_fields, host_traj_blocks, hostcheck, increments_of, make_params, refcall,
+                        relerr, set_lib_params)
+
+TOL = 1e-12  # host build: no FMA contraction, host libm -> differences only from the re-associated adjoint sums
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    return refcall.OracleLib()
+
+
+def oracle_qsat(oracle, st):
+    q = np.zeros_like(st.PAP)
+    for ibl in range(st.nblocks):
+        icend = min(st.nproma, st.ngptot - ibl * st.nproma)
+        q[ibl] = oracle.satur(np.ascontiguousarray(st.PAP[ibl]), np.ascontiguousarray(st.PT[ibl]), kfdia=icend)
+        q[ibl][:, icend:] = 0.0
+    return q
+
+
+@pytest.mark.parametrize("nproma,ngptot", [(32, 100), (100, 100), (1, 5), (48, 130)])
+def test_nl_columns(oracle, nproma, ngptot):
+    tab = c2.synthetic_table()
+    prm = make_params(tab)
+    set_lib_params(oracle, prm)
+    st = c2.state_from_table(tab, nproma, ngptot, poison_outputs=-5.0)
+    got = st.copy()
+    i, o = host_traj_blocks(got)
+    S = nproma * st.nlev
+    zero = B.Field()
+    zero.ptr = got.B_LOC.ctypes.data + 8 * 7 * S
+    zero.block_stride = 8 * S
+    assert hostcheck().hostcheck_nl(C.byref(prm), st.ptsphy, nproma, st.nlev, ngptot, C.byref(i), C.byref(o), zero, 0.0) == 0
+    for ibl in range(st.nblocks):
+        icend = min(nproma, ngptot - ibl * nproma)
+        qs = oracle.satur(np.ascontiguousarray(st.PAP[ibl]), np.ascontiguousarray(st.PT[ibl]), kfdia=icend)
+        inp = refcall.block_inputs(st, ibl, qs)
+        for a in inp.values():
+            a[:, icend:] = 1.0
+        want = oracle.cloudsc2(st.ptsphy, inp, kfdia=icend)
+        for n, a in refcall.state_outputs_block(got, ibl).items():
+            assert relerr(want[n][:, :icend], a[:, :icend]) <= TOL, (n, ibl)
+            if n != "covptot":
+                assert np.all(a[:, icend:] == -5.0), ("tail touched", n)
+    assert np.all(got.PCOVPTOT == 0.0) and np.all(got.B_LOC[:, 7] == 0.0)
+
+
+@pytest.mark.parametrize("flags", [dict(), dict(lregcl=True), dict(levapls2=True, lregcl=True), dict(ldrain1d=True)])
+def test_tl_ad_columns(oracle, flags):
+    tab = c2.random_table(137, 30, seed=4)
+    prm = make_params(tab, **flags)
+    set_lib_params(oracle, prm)
+    nproma, ngptot = 16, 30
+    st = c2.state_from_table(tab, nproma, ngptot)
+    nb, nlev = st.nblocks, st.nlev
+    qsat = oracle_qsat(oracle, st)
+    inc = increments_of(st, qsat)
+    hc = hostcheck()
+
+    got = st.copy()
+    i, o = host_traj_blocks(got, qsat)
+    tl = flat_fields("out", nb, nlev, nproma)
+    di, do_ = flat_block("in", inc), flat_block("out", tl)
+    assert hc.hostcheck_tl(C.byref(prm), st.ptsphy, nproma, nlev, ngptot, C.byref(i), C.byref(o), C.byref(di), C.byref(do_)) == 0
+
+    x = flat_fields("in", nb, nlev, nproma)
+    y = {n: a.copy() for n, a in tl.items()}
+    scratch = np.zeros((nb, nlev, nproma))
+    got2 = st.copy()
+    i2, o2 = host_traj_blocks(got2, qsat)
+    ai, ao = flat_block("in", x), flat_block("out", y)
+    assert hc.hostcheck_ad(C.byref(prm), st.ptsphy, nproma, nlev, ngptot, C.byref(i2), C.byref(o2), C.byref(ai), C.byref(ao),
+                           scratch.ctypes.data) == 0
+
+    ld = bool(flags.get("ldrain1d", False))
+    for ibl in range(nb):
+        icend = min(nproma, ngptot - ibl * nproma)
+        inp = refcall.block_inputs(st, ibl, qsat[ibl])
+        dinp = {n: np.ascontiguousarray(inc[n][ibl]) for n in inc}
+        for d in (inp, dinp):
+            for a in d.values():
+                a[:, icend:] = 1.0
+        o5, dout = oracle.cloudsc2tl(st.ptsphy, inp, dinp, kfdia=icend, ldrain1d=ld)
+        for n in dout:
+            assert relerr(dout[n][:, :icend], tl[n][ibl][:, :icend]) <= TOL, ("tl", n)
+        for n, a in refcall.state_outputs_block(got, ibl).items():
+            assert relerr(o5[n][:, :icend], a[:, :icend]) <= TOL, ("traj", n)
+        xr = refcall.new_inputs(nlev, nproma)
+        yr = {n: a.copy() for n, a in dout.items()}
+        oracle.cloudsc2ad(st.ptsphy, inp, xr, yr, kfdia=icend, ldrain1d=ld)
+        for n in xr:
+            assert relerr(xr[n][:, :icend], x[n][ibl][:, :icend]) <= TOL, ("ad", n)
+            assert np.all(x[n][ibl][:, icend:] == 0.0)
+        for n in y:
+            assert np.all(y[n][ibl][:, :icend] == 0.0), ("output adjoint not consumed", n)
+
+    # <TL x, TL x> = <x, AD TL x> per column (PSUPSAT excluded: the reference assigns its adjoint, cloudsc2ad.F90:1733)
+    for ibl in range(nb):
+        icend = min(nproma, ngptot - ibl * nproma)
+        n1 = sum((tl[n][ibl][:, :icend] ** 2).sum(axis=0) for n in tl)
+        n2 = sum((inc[n][ibl][:, :icend] * x[n][ibl][:, :icend]).sum(axis=0) for n in inc if n != "supsat")
+        n2s = (inc["supsat"][ibl][:, :icend] * x["supsat"][ibl][:, :icend] / st.ptsphy).sum(axis=0)  # corrected term
+        assert np.max(np.abs(n1 - n2 - n2s) / np.abs(n1)) < 1e4 * 2.2e-16
+
+
+def test_perturbed_nl_matches_explicit_perturbation(oracle):
+    """pert_lambda of cloudsc2_nl_launch = the Taylor test's x + lambda*(0.01 x) (cloudsc_driver_tl_mod.F90:200-215)."""
+    tab = c2.synthetic_table()
+    prm = make_params(tab)
+    set_lib_params(oracle, prm)
+    nproma = ngptot = 20
+    st = c2.state_from_table(tab, nproma, ngptot)
+    qsat = oracle_qsat(oracle, st)
+    lam = 1e-3
+    got = st.copy()
+    i, o = host_traj_blocks(got, qsat)
+    hostcheck().hostcheck_nl(C.byref(prm), st.ptsphy, nproma, st.nlev, ngptot, C.byref(i), C.byref(o), B.Field(), lam)
+    inp = refcall.block_inputs(st, 0, qsat[0])
+    pin = {n: a + lam * (a * 0.01) for n, a in inp.items()}
+    want = oracle.cloudsc2(st.ptsphy, pin)
+    for n, a in refcall.state_outputs_block(got, 0).items():
+        assert relerr(want[n], a) <= TOL, n

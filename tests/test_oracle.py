@@ -1,0 +1,138 @@
+"""CPU tests of the checker itself: the C restatement (oracle/cloudsc2_oracle.c) against
+  (a) golden vectors generated from the unmodified reference Fortran (tests/golden/, always available), and
+  (b) the reference Fortran itself (oracle/_ref), when it has been built in this container.
+"""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests.golden.make_golden import input_digest, table_inputs, tl_ad
+from tests.util import ROOT, c2, make_params, refcall, relerr, set_lib_params
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+META = json.load(open(os.path.join(GOLD, "drivers.json")))
+
+# the restatement follows the reference statement by statement and is compiled without FMA contraction like the
+# flang build of the reference: agreement is expected to the last bit; 1e-13 leaves room for another libm.
+ORACLE_TOL = 1e-13
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    if not refcall.have_oracle():
+        pytest.fail("oracle/libcloudsc2_oracle.so missing: run `make -C oracle oracle` (or __graft_entry__.build())")
+    return refcall.OracleLib()
+
+
+def _table(name):
+    info = META["fixtures"][name]
+    if name.startswith("evap"):
+        tab = c2.random_table(137, info["ncol"], seed=info["seed"])
+    else:
+        tab = c2.synthetic_table()
+        tab = {k: (v[:, : info["ncol"]] if isinstance(v, np.ndarray) else v) for k, v in tab.items()}
+    return tab, info
+
+
+def test_golden_nl(oracle):
+    tab, info = _table("nl_synth100")
+    g = np.load(os.path.join(GOLD, "nl_synth100.npz"))
+    set_lib_params(oracle, make_params(tab))
+    st, inp = table_inputs(oracle, tab, info["ncol"])
+    assert relerr(g["qsat"], inp["qsat"]) <= ORACLE_TOL
+    assert input_digest(inp) == info["digest"], "synthetic inputs or SATUR drifted from the fixture"
+    out = oracle.cloudsc2(st.ptsphy, inp)
+    for n, a in out.items():
+        assert relerr(g["out_" + n], a) <= ORACLE_TOL, n
+    # the golden data precipitates in every column (the reference's Taylor test needs that) and has rain and snow
+    assert np.all(np.abs(g["out_fplsn"][-1]) + np.abs(g["out_fplsl"][-1]) > 0)
+    assert np.any(g["out_fplsl"] > 0) and np.any(g["out_fplsn"] > 0)
+
+
+@pytest.mark.parametrize("lreg", [0, 1])
+def test_golden_tl_ad(oracle, lreg):
+    name = f"tlad_synth24_r{lreg}"
+    tab, info = _table(name)
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    set_lib_params(oracle, make_params(tab, lregcl=bool(lreg)))
+    st, inp = table_inputs(oracle, tab, info["ncol"])
+    assert input_digest(inp) == info["digest"]
+    out5, dout, x = tl_ad(oracle, st.ptsphy, inp)
+    for n in dout:
+        assert relerr(g["tl_" + n], dout[n]) <= ORACLE_TOL, ("tl", n)
+        assert relerr(g["traj_" + n], out5[n]) <= ORACLE_TOL, ("traj", n)
+    for n in x:
+        assert relerr(g["ad_" + n], x[n]) <= ORACLE_TOL, ("ad", n)
+
+
+def test_golden_evaporation_branch(oracle):
+    tab, info = _table("evap_rand24")
+    g = np.load(os.path.join(GOLD, "evap_rand24.npz"))
+    set_lib_params(oracle, make_params(tab, **info["flags"]))
+    st, inp = table_inputs(oracle, tab, info["ncol"])
+    assert input_digest(inp) == info["digest"]
+    out = oracle.cloudsc2(st.ptsphy, inp)
+    out5, dout, x = tl_ad(oracle, st.ptsphy, inp)
+    assert np.any(g["out_covptot"] != 0.0)
+    for n in out:
+        assert relerr(g["out_" + n], out[n]) <= ORACLE_TOL, n
+        assert relerr(g["tl_" + n], dout[n]) <= ORACLE_TOL, ("tl", n)
+    for n in x:
+        assert relerr(g["ad_" + n], x[n]) <= ORACLE_TOL, ("ad", n)
+
+
+def test_reference_h5_constants():
+    """config-files/reference.h5 (the reference's golden NL output) cannot be reproduced without the undistributed
+    input.h5, but it pins two things: RLSTT (-PFHPSN/PFPLSN, cloudsc2.F90:733) and the output conventions
+    (PCOVPTOT, TENDENCY_LOC_A, rain/snow species of CLD never written)."""
+    g = np.load(os.path.join(GOLD, "reference_h5.npz"))
+    prm = c2.default_params()
+    nz = g["PFPLSN"] != 0
+    assert nz.sum() == 4497
+    assert np.max(np.abs(-g["PFHPSN"][nz] / g["PFPLSN"][nz] / prm.rlstt - 1.0)) < 1e-15
+    assert not g["PCOVPTOT"].any() and not g["TENDENCY_LOC_A"].any() and not g["PFPLSL"].any()
+    assert not g["TENDENCY_LOC_CLD"][2:].any() and g["TENDENCY_LOC_CLD"][:2].any()
+    assert abs(np.abs(g["TENDENCY_LOC_T"]).sum() - 8.280448058210742e-02) < 1e-15
+
+
+@pytest.mark.skipif(not refcall.have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("flags", [dict(), dict(lregcl=True), dict(levapls2=True), dict(levapls2=True, lregcl=True)])
+def test_oracle_equals_reference(oracle, flags):
+    tab = c2.random_table(137, 48, seed=21)
+    prm = make_params(tab, **flags)
+    ref = refcall.RefLib()
+    set_lib_params(ref, prm)
+    set_lib_params(oracle, prm)
+    st, inp = table_inputs(ref, tab, 48)
+    assert np.array_equal(inp["qsat"], oracle.satur(inp["pap"], inp["t"]))
+    a, b = ref.cloudsc2(st.ptsphy, inp), oracle.cloudsc2(st.ptsphy, inp)
+    for n in a:
+        assert relerr(a[n], b[n]) <= ORACLE_TOL, ("nl", n)
+    ra, rb = tl_ad(ref, st.ptsphy, inp), tl_ad(oracle, st.ptsphy, inp)
+    for k in range(3):
+        for n in ra[k]:
+            assert relerr(ra[k][n], rb[k][n]) <= ORACLE_TOL, (k, n)
+
+
+@pytest.mark.skipif(not refcall.have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+def test_oracle_driver_equals_reference_driver(oracle):
+    """The OpenMP block loop used for the CPU baseline when the reference build cannot travel."""
+    import ctypes as C
+
+    tab = c2.synthetic_table()
+    prm = make_params(tab)
+    ref = refcall.RefLib()
+    set_lib_params(ref, prm)
+    set_lib_params(oracle, prm)
+    a = c2.state_from_table(tab, 32, 230)
+    b = a.copy()
+    ref.driver(0, 2, 32, a.nlev, 230, a.ptsphy, a.driver_arrays())
+    dp = C.POINTER(C.c_double)
+    oracle.lib.oracle_driver_nl.argtypes = [C.c_int] * 4 + [C.c_double] + [dp] * 18
+    oracle.lib.oracle_driver_nl(2, 32, b.nlev, 230, b.ptsphy, *[x.ctypes.data_as(dp) for x in b.driver_arrays()])
+    for n in a.outputs():
+        assert np.array_equal(a.outputs()[n], b.outputs()[n]), n
