@@ -6,7 +6,8 @@ the same driver interface.  Importing the package loads the HIP library and rais
 is no CPU fallback.
 """
 from . import binding  # noqa: F401  (raises ImportError when libcloudsc2_hip.so is missing)
-from .binding import Cloudsc2Error, Params, default_params, device_available, taylor_verdict, adjoint_verdict  # noqa: F401
+from .binding import (Cloudsc2Error, Params, adjoint_verdict, default_params, device_available, get_math_mode,  # noqa: F401
+                      set_math_mode, taylor_verdict)
 from .state import (Cloudsc2State, bytes_per_column, ceta_from_table, column_range, nblocks_of, random_table,  # noqa: F401
                     state_from_table, synthetic_table, validate_l1)
 from .driver import DeviceState, FlatFields, cloudsc_driver, cloudsc_driver_ad, cloudsc_driver_tl, run_state  # noqa: F401

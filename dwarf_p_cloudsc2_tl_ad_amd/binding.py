@@ -94,6 +94,9 @@ def _load() -> C.CDLL:
     lib.cloudsc2_params_default.restype = None
     lib.cloudsc2_last_error.restype = C.c_char_p
     lib.cloudsc2_device_available.restype = C.c_int
+    lib.cloudsc2_set_math_mode.argtypes = [C.c_int]
+    lib.cloudsc2_set_math_mode.restype = None
+    lib.cloudsc2_get_math_mode.restype = C.c_int
     lib.cloudsc2_nl_launch.argtypes = [pp, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(Inputs), C.POINTER(Outputs),
                                        Field, C.c_double, C.c_void_p]
     lib.cloudsc2_satur_launch.argtypes = [pp, C.c_int, C.c_int, C.c_int, Field, Field, Field, C.c_void_p]
@@ -124,7 +127,8 @@ def _load() -> C.CDLL:
 lib = _load()
 
 # every symbol include/cloudsc2_hip.h declares
-EXPORTED = ("cloudsc2_params_default", "cloudsc2_last_error", "cloudsc2_device_available", "cloudsc2_nl_launch",
+EXPORTED = ("cloudsc2_params_default", "cloudsc2_last_error", "cloudsc2_device_available", "cloudsc2_set_math_mode",
+            "cloudsc2_get_math_mode", "cloudsc2_nl_launch",
             "cloudsc2_satur_launch", "cloudsc2_tl_launch", "cloudsc2_ad_launch", "cloudsc2_taylor_sums_launch",
             "cloudsc2_adjoint_norms_launch", "cloudsc2_nl_run", "cloudsc2_tl_taylor_run", "cloudsc2_ad_symmetry_run",
             "cloudsc2_release_workspace", "cloudsc2_taylor_verdict", "cloudsc2_adjoint_verdict")
@@ -144,6 +148,15 @@ def default_params(ceta=None, *, lregcl: bool = False, levapls2: bool = False, l
     if ceta is not None:
         p.set_ceta(ceta)
     return p
+
+
+def set_math_mode(precise: bool) -> None:
+    """False: fast math (default); True: IEEE division + libm exp in the reference's operation order."""
+    lib.cloudsc2_set_math_mode(int(bool(precise)))
+
+
+def get_math_mode() -> bool:
+    return bool(lib.cloudsc2_get_math_mode())
 
 
 def device_available() -> bool:

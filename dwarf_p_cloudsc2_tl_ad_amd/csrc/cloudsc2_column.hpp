@@ -44,20 +44,43 @@ struct InPtrsRW {
   double *paph, *pap, *q, *qsat, *t, *l, *i, *lude, *lu, *mfu, *mfd, *gt, *gq, *gl, *gi, *supsat;
 };
 
+// Kernel argument blocks.  Each kernel takes exactly one of these by value; on the device the column functions read
+// it in place from the kernel-argument segment through a constant-address-space pointer (see C2_LAUNDER).
+struct NlArgs {
+  Consts c; Geom g; Strides s; InPtrs in; OutPtrs out; const LevelTab* tab;
+  double* zero_plane; long long zero_stride; real_t lam;
+};
+struct TlArgs {
+  Consts c; Geom g; Strides s, sp; InPtrs in; OutPtrs out; InPtrs din; OutPtrs dout; const LevelTab* tab;
+};
+struct AdArgs {
+  Consts c; Geom g; Strides s, sa; InPtrs in; OutPtrs out; InPtrsRW ain; OutPtrs aout; const LevelTab* tab;
+  double* scratch;
+};
+typedef const C2_CONST_AS NlArgs* NlArgsP;
+typedef const C2_CONST_AS TlArgs* TlArgsP;
+typedef const C2_CONST_AS AdArgs* AdArgsP;
+typedef const C2_CONST_AS InPtrs* InPtrsP;
+typedef const C2_CONST_AS OutPtrs* OutPtrsP;
+typedef const C2_CONST_AS InPtrsRW* InPtrsRWP;
+typedef const C2_CONST_AS LevelTab* LevelTabP;
+typedef const C2_CONST_AS Geom* GeomP;
+typedef const C2_CONST_AS Strides* StridesP;
+
 struct LaneOff {
   long long full, half, cml, clv, loc;
 };
 
-C2_HD bool lane_setup(const Geom& g, const Strides& s, long long gcol, LaneOff& o, bool& active) {
-  if (gcol >= g.ncols_pad) return false;
-  long long ibl = gcol / g.nproma;
-  long long jl = gcol - ibl * g.nproma;
-  o.full = ibl * s.full + jl;
-  o.half = ibl * s.half + jl;
-  o.cml = ibl * s.cml + jl;
-  o.clv = ibl * s.clv + jl;
-  o.loc = ibl * s.loc + jl;
-  active = gcol < g.ngptot;
+C2_HD bool lane_setup(GeomP g, StridesP s, long long gcol, LaneOff& o, bool& active) {
+  if (gcol >= g->ncols_pad) return false;
+  long long ibl = gcol / g->nproma;
+  long long jl = gcol - ibl * g->nproma;
+  o.full = ibl * s->full + jl;
+  o.half = ibl * s->half + jl;
+  o.cml = ibl * s->cml + jl;
+  o.clv = ibl * s->clv + jl;
+  o.loc = ibl * s->loc + jl;
+  active = gcol < g->ngptot;
   return true;
 }
 
@@ -67,25 +90,25 @@ struct RawLevel {
 };
 
 template <bool HAS_QSAT>
-C2_HD void load_raw(const InPtrs& p, const LaneOff& o, int nproma, int jk, bool full_level, RawLevel& r) {
+C2_HD void load_raw(InPtrsP p, const LaneOff& o, int nproma, int jk, bool full_level, RawLevel& r) {
   const long long d = (long long)jk * nproma;
-  r.paph = p.paph[o.half + d];
+  r.paph = p->paph[o.half + d];
   if (full_level) {
-    r.pap = p.pap[o.full + d];
-    r.q = p.q[o.full + d];
-    r.t = p.t[o.full + d];
-    r.l = p.l[o.clv + d];
-    r.i = p.i[o.clv + d];
-    r.lude = p.lude[o.full + d];
-    r.lu = p.lu[o.full + d];
-    r.mfu = p.mfu[o.full + d];
-    r.mfd = p.mfd[o.full + d];
-    r.gt = p.gt[o.cml + d];
-    r.gq = p.gq[o.cml + d];
-    r.gl = p.gl[o.cml + d];
-    r.gi = p.gi[o.cml + d];
-    r.supsat = p.supsat[o.full + d];
-    if (HAS_QSAT) r.qsat = p.qsat[o.full + d];
+    r.pap = p->pap[o.full + d];
+    r.q = p->q[o.full + d];
+    r.t = p->t[o.full + d];
+    r.l = p->l[o.clv + d];
+    r.i = p->i[o.clv + d];
+    r.lude = p->lude[o.full + d];
+    r.lu = p->lu[o.full + d];
+    r.mfu = p->mfu[o.full + d];
+    r.mfd = p->mfd[o.full + d];
+    r.gt = p->gt[o.cml + d];
+    r.gq = p->gq[o.cml + d];
+    r.gl = p->gl[o.cml + d];
+    r.gi = p->gi[o.cml + d];
+    r.supsat = p->supsat[o.full + d];
+    if (HAS_QSAT) r.qsat = p->qsat[o.full + d];
   }
 }
 
@@ -112,18 +135,22 @@ C2_HD void make_level_in(const RawLevel& cur, const RawLevel& nxt, real_t paph_s
 
 // Tropopause pre-scan (cloudsc2.F90:315-326): the last band level whose first-guess T exceeds the one below.
 template <bool PERT>
-C2_HD real_t tropopause(const Consts& c, const LevelTab* tab, const InPtrs& p, const LaneOff& o, const Geom& g, real_t lam) {
+C2_HD real_t tropopause(ConstsP c, LevelTabP tab, InPtrsP p, const LaneOff& o, GeomP g, real_t lam) {
   real_t ztrpaus = 0.1;
-  if (g.kb1 > g.kb0) {
-    long long d = (long long)g.kb0 * g.nproma;
-    real_t t0 = p.t[o.full + d], g0 = p.gt[o.cml + d];
+  const int kb0 = g->kb0, kb1 = g->kb1, nproma = g->nproma;
+  if (kb1 > kb0) {
+    const real_t ptsphy = c->ptsphy;
+    const double* pt = p->t;
+    const double* pg = p->gt;
+    long long d = (long long)kb0 * nproma;
+    real_t t0 = pt[o.full + d], g0 = pg[o.cml + d];
     if (PERT) { t0 = pert(t0, lam); g0 = pert(g0, lam); }
-    real_t tup = t0 + c.ptsphy * g0;
-    for (int jk = g.kb0; jk < g.kb1; ++jk) {
-      long long d1 = (long long)(jk + 1) * g.nproma;
-      real_t t1 = p.t[o.full + d1], g1 = p.gt[o.cml + d1];
+    real_t tup = t0 + ptsphy * g0;
+    for (int jk = kb0; jk < kb1; ++jk) {
+      long long d1 = (long long)(jk + 1) * nproma;
+      real_t t1 = pt[o.full + d1], g1 = pg[o.cml + d1];
       if (PERT) { t1 = pert(t1, lam); g1 = pert(g1, lam); }
-      real_t tdn = t1 + c.ptsphy * g1;
+      real_t tdn = t1 + ptsphy * g1;
       real_t ce = tab->ceta[jk];
       if (ce > 0.1 && ce < 0.4 && tup > tdn) ztrpaus = ce;
       tup = tdn;
@@ -132,76 +159,98 @@ C2_HD real_t tropopause(const Consts& c, const LevelTab* tab, const InPtrs& p, c
   return ztrpaus;
 }
 
-C2_HD void store_out(const OutPtrs& p, const LaneOff& o, int nproma, int jk, const Consts& c, const LevelOut& v) {
+C2_HD void store_out(OutPtrsP p, const LaneOff& o, int nproma, int jk, ConstsP c, const LevelOut& v) {
   const long long d = (long long)jk * nproma;
-  if (p.tent) p.tent[o.loc + d] = v.tent;
-  if (p.tenq) p.tenq[o.loc + d] = v.tenq;
-  if (p.tenl) p.tenl[o.loc + d] = v.tenl;
-  if (p.teni) p.teni[o.loc + d] = v.teni;
-  if (p.clc) p.clc[o.full + d] = v.clc;
-  if (p.covptot) p.covptot[o.full + d] = v.covptot;
+  if (p->tent) p->tent[o.loc + d] = v.tent;
+  if (p->tenq) p->tenq[o.loc + d] = v.tenq;
+  if (p->tenl) p->tenl[o.loc + d] = v.tenl;
+  if (p->teni) p->teni[o.loc + d] = v.teni;
+  if (p->clc) p->clc[o.full + d] = v.clc;
+  if (p->covptot) p->covptot[o.full + d] = v.covptot;
   const long long d1 = d + nproma;
-  if (p.fplsl) p.fplsl[o.half + d1] = v.fplsl;
-  if (p.fplsn) p.fplsn[o.half + d1] = v.fplsn;
+  if (p->fplsl) p->fplsl[o.half + d1] = v.fplsl;
+  if (p->fplsn) p->fplsn[o.half + d1] = v.fplsn;
   // enthalpy fluxes (cloudsc2.F90:732-733)
-  if (p.fhpsl) p.fhpsl[o.half + d1] = -v.fplsl * c.rlvtt;
-  if (p.fhpsn) p.fhpsn[o.half + d1] = -v.fplsn * c.rlstt;
+  if (p->fhpsl) p->fhpsl[o.half + d1] = -v.fplsl * c->rlvtt;
+  if (p->fhpsn) p->fhpsn[o.half + d1] = -v.fplsn * c->rlstt;
 }
 
-C2_HD void store_top(const OutPtrs& p, const LaneOff& o, const Consts& c) {
+C2_HD void store_top(OutPtrsP p, const LaneOff& o, ConstsP c) {
   // fluxes at the model top are zero (cloudsc2.F90:308-309); enthalpy fluxes -0*RLVTT (:732-733)
   const real_t z = 0.0;
-  if (p.fplsl) p.fplsl[o.half] = z;
-  if (p.fplsn) p.fplsn[o.half] = z;
-  if (p.fhpsl) p.fhpsl[o.half] = -z * c.rlvtt;
-  if (p.fhpsn) p.fhpsn[o.half] = -z * c.rlstt;
+  if (p->fplsl) p->fplsl[o.half] = z;
+  if (p->fplsn) p->fplsn[o.half] = z;
+  if (p->fhpsl) p->fhpsl[o.half] = -z * c->rlvtt;
+  if (p->fhpsn) p->fhpsn[o.half] = -z * c->rlstt;
+}
+
+C2_HD void level_cst(LevelTabP tab, int jk, bool last, LevelCst& k) {
+  k.ceta = tab->ceta[jk];
+  k.zscalm = tab->zscalm[jk];
+  k.last = last;
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // SATUR for one column
 // ---------------------------------------------------------------------------------------------------------
-C2_HD void satur_column(long long gcol, const Consts& c, const Geom& g, const Strides& s, const double* pap, const double* t,
-                        double* qsat) {
+struct SaturArgs {
+  Consts c; Geom g; Strides s; const double* pap; const double* t; double* qsat;
+};
+typedef const C2_CONST_AS SaturArgs* SaturArgsP;
+
+template <bool P>
+C2_HD void satur_column(long long gcol, SaturArgsP a) {
   LaneOff o; bool active;
-  if (!lane_setup(g, s, gcol, o, active)) return;
+  if (!lane_setup(&a->g, &a->s, gcol, o, active)) return;
   if (!active) return;
-  for (int jk = 0; jk < g.nlev; ++jk) {
-    long long d = (long long)jk * g.nproma;
-    qsat[o.full + d] = satur_point(c, pap[o.full + d], t[o.full + d]);
+  const int nlev = a->g.nlev, nproma = a->g.nproma;
+  const double* pap = a->pap;
+  const double* t = a->t;
+  double* qsat = a->qsat;
+  for (int jk = 0; jk < nlev; ++jk) {
+    long long d = (long long)jk * nproma;
+    qsat[o.full + d] = satur_point<P>(&a->c, pap[o.full + d], t[o.full + d]);
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // NL: SATUR (optionally fused) + CLOUDSC2 for one column
 // ---------------------------------------------------------------------------------------------------------
-template <bool HAS_QSAT, bool PERT>
-C2_HD void nl_column(long long gcol, const Consts& c, const LevelTab* tab, const Geom& g, const Strides& s, const InPtrs& in,
-                     const OutPtrs& out, double* zero_plane, long long zero_stride, real_t lam) {
+template <bool HAS_QSAT, bool PERT, bool P>
+C2_HD void nl_column(long long gcol, NlArgsP a) {
   LaneOff o; bool active;
-  if (!lane_setup(g, s, gcol, o, active)) return;
+  if (!lane_setup(&a->g, &a->s, gcol, o, active)) return;
+  const int nlev = a->g.nlev, nproma = a->g.nproma;
+  const real_t lam = PERT ? a->lam : 0.0;
+  double* zero_plane = a->zero_plane;
   long long ozero = 0;
   if (zero_plane) {
-    long long ibl = gcol / g.nproma;
-    ozero = ibl * zero_stride + (gcol - ibl * g.nproma);
+    long long ibl = gcol / nproma;
+    ozero = ibl * a->zero_stride + (gcol - ibl * nproma);
   }
   if (!active) {
     // padded tail of the last block: the driver zeroes the whole block's PCOVPTOT and CLD(:,:,NCLV)
     // (cloudsc_driver_mod.F90:87-88); nothing else is touched.
-    for (int jk = 0; jk < g.nlev; ++jk) {
-      long long d = (long long)jk * g.nproma;
-      if (out.covptot) out.covptot[o.full + d] = 0.0;
+    double* cov = a->out.covptot;
+    for (int jk = 0; jk < nlev; ++jk) {
+      long long d = (long long)jk * nproma;
+      if (cov) cov[o.full + d] = 0.0;
       if (zero_plane) zero_plane[ozero + d] = 0.0;
     }
     return;
   }
+  LevelTabP tab = (LevelTabP)a->tab;
+  ConstsP c = &a->c;
+  InPtrsP in = &a->in;
+  OutPtrsP out = &a->out;
 
-  real_t ztrpaus = tropopause<PERT>(c, tab, in, o, g, lam);
+  real_t ztrpaus = tropopause<PERT>(c, tab, in, o, &a->g, lam);
   RhCrit rh;
   rhcrit_setup(ztrpaus, rh);
 
   real_t paph_surf = 0.0;
-  if (c.evap) {
-    paph_surf = in.paph[o.half + (long long)g.nlev * g.nproma];
+  if (c->evap) {
+    paph_surf = in->paph[o.half + (long long)nlev * nproma];
     if (PERT) paph_surf = pert(paph_surf, lam);
   }
 
@@ -209,26 +258,31 @@ C2_HD void nl_column(long long gcol, const Consts& c, const LevelTab* tab, const
 
   Carry cy; cy.rfl = 0.0; cy.sfl = 0.0; cy.covptot = 0.0;
   RawLevel cur, nxt;
-  load_raw<HAS_QSAT>(in, o, g.nproma, 0, true, cur);
-  if (!HAS_QSAT) cur.qsat = satur_point(c, cur.pap, cur.t);
+  load_raw<HAS_QSAT>(in, o, nproma, 0, true, cur);
+  if (!HAS_QSAT) cur.qsat = satur_point<P>(c, cur.pap, cur.t);
   if (PERT) perturb_raw(cur, lam, true);
 
-  for (int jk = 0; jk < g.nlev; ++jk) {
-    const bool last = (jk == g.nlev - 1);
+  for (int jk = 0; jk < nlev; ++jk) {
+    const bool last = (jk == nlev - 1);
+    C2_LAUNDER(a);
+    c = &a->c; in = &a->in; out = &a->out; tab = (LevelTabP)a->tab;
     nxt = cur;
     nxt.lu = 0.0;
-    load_raw<HAS_QSAT>(in, o, g.nproma, jk + 1, !last, nxt);
-    if (!last && !HAS_QSAT) nxt.qsat = satur_point(c, nxt.pap, nxt.t);
+    load_raw<HAS_QSAT>(in, o, nproma, jk + 1, !last, nxt);
+    if (!last && !HAS_QSAT) nxt.qsat = satur_point<P>(c, nxt.pap, nxt.t);
     if (PERT) perturb_raw(nxt, lam, !last);
 
-    LevelCst k; k.ceta = tab->ceta[jk]; k.zscalm = tab->zscalm[jk]; k.last = last;
+    LevelCst k;
+    level_cst(tab, jk, last, k);
     LevelIn x;
     make_level_in(cur, nxt, paph_surf, x);
     LevelTraj tr;
     LevelOut lo;
-    level_forward(c, k, rh, x, cy, tr, lo);
-    store_out(out, o, g.nproma, jk, c, lo);
-    if (zero_plane) zero_plane[ozero + (long long)jk * g.nproma] = 0.0;
+    level_forward<P>(c, k, rh, x, cy, tr, lo);
+    C2_LAUNDER(a);
+    out = &a->out; c = &a->c;
+    store_out(out, o, nproma, jk, c, lo);
+    if (zero_plane) zero_plane[ozero + (long long)jk * nproma] = 0.0;
     cur = nxt;
   }
 }
@@ -236,22 +290,26 @@ C2_HD void nl_column(long long gcol, const Consts& c, const LevelTab* tab, const
 // ---------------------------------------------------------------------------------------------------------
 // TL: SATUR (optionally fused) + CLOUDSC2TL for one column
 // ---------------------------------------------------------------------------------------------------------
-template <bool HAS_QSAT>
-C2_HD void tl_column(long long gcol, const Consts& c, const LevelTab* tab, const Geom& g, const Strides& s, const Strides& sp,
-                     const InPtrs& in, const OutPtrs& out, const InPtrs& din, const OutPtrs& dout) {
+template <bool HAS_QSAT, bool P>
+C2_HD void tl_column(long long gcol, TlArgsP a) {
   LaneOff o, op; bool active;
-  if (!lane_setup(g, s, gcol, o, active)) return;
-  lane_setup(g, sp, gcol, op, active);
+  if (!lane_setup(&a->g, &a->s, gcol, o, active)) return;
+  lane_setup(&a->g, &a->sp, gcol, op, active);
   if (!active) return;
+  const int nlev = a->g.nlev, nproma = a->g.nproma;
+  LevelTabP tab = (LevelTabP)a->tab;
+  ConstsP c = &a->c;
+  InPtrsP in = &a->in, din = &a->din;
+  OutPtrsP out = &a->out, dout = &a->dout;
 
-  real_t ztrpaus = tropopause<false>(c, tab, in, o, g, 0.0);
+  real_t ztrpaus = tropopause<false>(c, tab, in, o, &a->g, 0.0);
   RhCrit rh;
   rhcrit_setup(ztrpaus, rh);
 
   real_t paph_surf = 0.0, dpaph_surf = 0.0;
-  if (c.evap) {
-    paph_surf = in.paph[o.half + (long long)g.nlev * g.nproma];
-    dpaph_surf = din.paph[op.half + (long long)g.nlev * g.nproma];
+  if (c->evap) {
+    paph_surf = in->paph[o.half + (long long)nlev * nproma];
+    dpaph_surf = din->paph[op.half + (long long)nlev * nproma];
   }
 
   store_top(out, o, c);
@@ -260,28 +318,35 @@ C2_HD void tl_column(long long gcol, const Consts& c, const LevelTab* tab, const
   Carry cy; cy.rfl = 0.0; cy.sfl = 0.0; cy.covptot = 0.0;
   Carry dcy; dcy.rfl = 0.0; dcy.sfl = 0.0; dcy.covptot = 0.0;
   RawLevel cur, nxt, dcur, dnxt;
-  load_raw<HAS_QSAT>(in, o, g.nproma, 0, true, cur);
-  if (!HAS_QSAT) cur.qsat = satur_point(c, cur.pap, cur.t);
-  load_raw<true>(din, op, g.nproma, 0, true, dcur);
+  load_raw<HAS_QSAT>(in, o, nproma, 0, true, cur);
+  if (!HAS_QSAT) cur.qsat = satur_point<P>(c, cur.pap, cur.t);
+  load_raw<true>(din, op, nproma, 0, true, dcur);
 
-  for (int jk = 0; jk < g.nlev; ++jk) {
-    const bool last = (jk == g.nlev - 1);
+  for (int jk = 0; jk < nlev; ++jk) {
+    const bool last = (jk == nlev - 1);
+    C2_LAUNDER(a);
+    c = &a->c; in = &a->in; din = &a->din; tab = (LevelTabP)a->tab;
     nxt = cur; dnxt = dcur;
     nxt.lu = 0.0; dnxt.lu = 0.0;
-    load_raw<HAS_QSAT>(in, o, g.nproma, jk + 1, !last, nxt);
-    load_raw<true>(din, op, g.nproma, jk + 1, !last, dnxt);
-    if (!last && !HAS_QSAT) nxt.qsat = satur_point(c, nxt.pap, nxt.t);
+    load_raw<HAS_QSAT>(in, o, nproma, jk + 1, !last, nxt);
+    load_raw<true>(din, op, nproma, jk + 1, !last, dnxt);
+    if (!last && !HAS_QSAT) nxt.qsat = satur_point<P>(c, nxt.pap, nxt.t);
 
-    LevelCst k; k.ceta = tab->ceta[jk]; k.zscalm = tab->zscalm[jk]; k.last = last;
+    LevelCst k;
+    level_cst(tab, jk, last, k);
     LevelIn x, dx;
     make_level_in(cur, nxt, paph_surf, x);
     make_level_in(dcur, dnxt, dpaph_surf, dx);
     LevelTraj tr;
     LevelOut lo, dlo;
-    level_forward(c, k, rh, x, cy, tr, lo);
+    level_forward<P>(c, k, rh, x, cy, tr, lo);
+    C2_LAUNDER(a);
+    c = &a->c;
     level_tl(c, k, x, tr, dx, dcy, dlo);
-    store_out(out, o, g.nproma, jk, c, lo);
-    store_out(dout, op, g.nproma, jk, c, dlo);
+    C2_LAUNDER(a);
+    c = &a->c; out = &a->out; dout = &a->dout;
+    store_out(out, o, nproma, jk, c, lo);
+    store_out(dout, op, nproma, jk, c, dlo);
     cur = nxt;
     dcur = dnxt;
   }
@@ -292,44 +357,55 @@ C2_HD void tl_column(long long gcol, const Consts& c, const LevelTab* tab, const
 // trajectory outputs PFPLSL5/PFPLSN5 that have to be written anyway, the precipitation cover goes to `scratch`),
 // then the reverse sweep re-evaluates each level's trajectory and applies the transposed level.
 // ---------------------------------------------------------------------------------------------------------
-template <bool HAS_QSAT>
-C2_HD void ad_column(long long gcol, const Consts& c, const LevelTab* tab, const Geom& g, const Strides& s, const Strides& sa,
-                     const InPtrs& in, const OutPtrs& out, const InPtrsRW& ain, const OutPtrs& aout, double* scratch) {
+template <bool HAS_QSAT, bool P>
+C2_HD void ad_column(long long gcol, AdArgsP a) {
   LaneOff o, oa; bool active;
-  if (!lane_setup(g, s, gcol, o, active)) return;
-  lane_setup(g, sa, gcol, oa, active);
+  if (!lane_setup(&a->g, &a->s, gcol, o, active)) return;
+  lane_setup(&a->g, &a->sa, gcol, oa, active);
   if (!active) return;
+  const int nlev = a->g.nlev, nproma = a->g.nproma;
+  LevelTabP tab = (LevelTabP)a->tab;
+  ConstsP c = &a->c;
+  InPtrsP in = &a->in;
+  OutPtrsP out = &a->out, aout = &a->aout;
+  InPtrsRWP ain = &a->ain;
+  double* scratch = a->scratch;
 
   // scratch: (NPROMA, NLEV, NBLOCKS) contiguous
-  const long long osc = (gcol / g.nproma) * ((long long)g.nproma * g.nlev) + (gcol % g.nproma);
+  const long long osc = (gcol / nproma) * ((long long)nproma * nlev) + (gcol % nproma);
 
-  real_t ztrpaus = tropopause<false>(c, tab, in, o, g, 0.0);
+  real_t ztrpaus = tropopause<false>(c, tab, in, o, &a->g, 0.0);
   RhCrit rh;
   rhcrit_setup(ztrpaus, rh);
   real_t paph_surf = 0.0;
-  if (c.evap) paph_surf = in.paph[o.half + (long long)g.nlev * g.nproma];
+  if (c->evap) paph_surf = in->paph[o.half + (long long)nlev * nproma];
 
   // ---- forward sweep (cloudsc2ad.F90:366-866) ----
   store_top(out, o, c);
   {
     Carry cy; cy.rfl = 0.0; cy.sfl = 0.0; cy.covptot = 0.0;
     RawLevel cur, nxt;
-    load_raw<HAS_QSAT>(in, o, g.nproma, 0, true, cur);
-    if (!HAS_QSAT) cur.qsat = satur_point(c, cur.pap, cur.t);
-    for (int jk = 0; jk < g.nlev; ++jk) {
-      const bool last = (jk == g.nlev - 1);
+    load_raw<HAS_QSAT>(in, o, nproma, 0, true, cur);
+    if (!HAS_QSAT) cur.qsat = satur_point<P>(c, cur.pap, cur.t);
+    for (int jk = 0; jk < nlev; ++jk) {
+      const bool last = (jk == nlev - 1);
+      C2_LAUNDER(a);
+      c = &a->c; in = &a->in; tab = (LevelTabP)a->tab;
       nxt = cur;
       nxt.lu = 0.0;
-      load_raw<HAS_QSAT>(in, o, g.nproma, jk + 1, !last, nxt);
-      if (!last && !HAS_QSAT) nxt.qsat = satur_point(c, nxt.pap, nxt.t);
-      LevelCst k; k.ceta = tab->ceta[jk]; k.zscalm = tab->zscalm[jk]; k.last = last;
+      load_raw<HAS_QSAT>(in, o, nproma, jk + 1, !last, nxt);
+      if (!last && !HAS_QSAT) nxt.qsat = satur_point<P>(c, nxt.pap, nxt.t);
+      LevelCst k;
+      level_cst(tab, jk, last, k);
       LevelIn x;
       make_level_in(cur, nxt, paph_surf, x);
-      scratch[osc + (long long)jk * g.nproma] = cy.covptot;  // ZCOVPTOT5(JK-1)
+      scratch[osc + (long long)jk * nproma] = cy.covptot;  // ZCOVPTOT5(JK-1)
       LevelTraj tr;
       LevelOut lo;
-      level_forward(c, k, rh, x, cy, tr, lo);
-      store_out(out, o, g.nproma, jk, c, lo);
+      level_forward<P>(c, k, rh, x, cy, tr, lo);
+      C2_LAUNDER(a);
+      c = &a->c; out = &a->out;
+      store_out(out, o, nproma, jk, c, lo);
       cur = nxt;
     }
   }
@@ -338,94 +414,102 @@ C2_HD void ad_column(long long gcol, const Consts& c, const LevelTab* tab, const
   Carry acy; acy.rfl = 0.0; acy.sfl = 0.0; acy.covptot = 0.0;
   real_t paph_pending = 0.0;  // contribution of level jk+1 to the PAPHP1 adjoint at half level jk+1
   real_t surf_acc = 0.0;      // PAPHP1(KLEV+1) adjoint, written once at the end
-  for (int jk = g.nlev - 1; jk >= 0; --jk) {
-    const bool last = (jk == g.nlev - 1);
-    const long long d = (long long)jk * g.nproma;
-    const long long d1 = d + g.nproma;
+  for (int jk = nlev - 1; jk >= 0; --jk) {
+    const bool last = (jk == nlev - 1);
+    const long long d = (long long)jk * nproma;
+    const long long d1 = d + nproma;
+    C2_LAUNDER(a);
+    c = &a->c; in = &a->in; out = &a->out; tab = (LevelTabP)a->tab;
     RawLevel cur, nxt;
-    load_raw<HAS_QSAT>(in, o, g.nproma, jk, true, cur);
-    if (!HAS_QSAT) cur.qsat = satur_point(c, cur.pap, cur.t);
+    load_raw<HAS_QSAT>(in, o, nproma, jk, true, cur);
+    if (!HAS_QSAT) cur.qsat = satur_point<P>(c, cur.pap, cur.t);
     nxt = cur;
-    nxt.paph = in.paph[o.half + d1];
-    nxt.lu = last ? 0.0 : in.lu[o.full + d1];
-    LevelCst k; k.ceta = tab->ceta[jk]; k.zscalm = tab->zscalm[jk]; k.last = last;
+    nxt.paph = in->paph[o.half + d1];
+    nxt.lu = last ? 0.0 : in->lu[o.full + d1];
+    LevelCst k;
+    level_cst(tab, jk, last, k);
     LevelIn x;
     make_level_in(cur, nxt, paph_surf, x);
     Carry cy;
-    cy.rfl = out.fplsl[o.half + d];  // ZRFL5(JK) = PFPLSL5(JK)
-    cy.sfl = out.fplsn[o.half + d];
+    cy.rfl = out->fplsl[o.half + d];  // ZRFL5(JK) = PFPLSL5(JK)
+    cy.sfl = out->fplsn[o.half + d];
     cy.covptot = scratch[osc + d];
     LevelTraj tr;
     LevelOut lo;
-    level_forward(c, k, rh, x, cy, tr, lo);
+    level_forward<P>(c, k, rh, x, cy, tr, lo);
 
     // output adjoints of this level; enthalpy-flux adjoints folded in (cloudsc2ad.F90:914-921)
+    C2_LAUNDER(a);
+    c = &a->c; aout = &a->aout;
     LevelOut ya;
-    ya.tent = aout.tent[oa.loc + d];
-    ya.tenq = aout.tenq[oa.loc + d];
-    ya.tenl = aout.tenl[oa.loc + d];
-    ya.teni = aout.teni[oa.loc + d];
-    ya.clc = aout.clc[oa.full + d];
-    ya.covptot = aout.covptot[oa.full + d];
-    ya.fplsn = aout.fplsn[oa.half + d1] - aout.fhpsn[oa.half + d1] * c.rlstt;
-    ya.fplsl = aout.fplsl[oa.half + d1] - aout.fhpsl[oa.half + d1] * c.rlvtt;
+    ya.tent = aout->tent[oa.loc + d];
+    ya.tenq = aout->tenq[oa.loc + d];
+    ya.tenl = aout->tenl[oa.loc + d];
+    ya.teni = aout->teni[oa.loc + d];
+    ya.clc = aout->clc[oa.full + d];
+    ya.covptot = aout->covptot[oa.full + d];
+    ya.fplsn = aout->fplsn[oa.half + d1] - aout->fhpsn[oa.half + d1] * c->rlstt;
+    ya.fplsl = aout->fplsl[oa.half + d1] - aout->fhpsl[oa.half + d1] * c->rlvtt;
 
     LevelIn ax;
     level_ad(c, k, x, tr, ya, acy, ax);
 
     // accumulate input adjoints (cloudsc2ad.F90:1723-1738; PSUPSAT assigned, :1733)
-    ain.pap[oa.full + d] += ax.pap;
-    ain.q[oa.full + d] += ax.q;
-    ain.qsat[oa.full + d] += ax.qs;
-    ain.t[oa.full + d] += ax.t;
-    ain.l[oa.clv + d] += ax.l;
-    ain.i[oa.clv + d] += ax.i;
-    ain.lude[oa.full + d] += ax.lude;
-    ain.mfu[oa.full + d] += ax.mfu;
-    ain.mfd[oa.full + d] += ax.mfd;
-    ain.gt[oa.cml + d] += ax.gt;
-    ain.gq[oa.cml + d] += ax.gq;
-    ain.gl[oa.cml + d] += ax.gl;
-    ain.gi[oa.cml + d] += ax.gi;
-    ain.supsat[oa.full + d] = ax.supsat;
-    if (!last) ain.lu[oa.full + d1] += ax.lu_k1;
+    C2_LAUNDER(a);
+    ain = &a->ain; aout = &a->aout;
+    ain->pap[oa.full + d] += ax.pap;
+    ain->q[oa.full + d] += ax.q;
+    ain->qsat[oa.full + d] += ax.qs;
+    ain->t[oa.full + d] += ax.t;
+    ain->l[oa.clv + d] += ax.l;
+    ain->i[oa.clv + d] += ax.i;
+    ain->lude[oa.full + d] += ax.lude;
+    ain->mfu[oa.full + d] += ax.mfu;
+    ain->mfd[oa.full + d] += ax.mfd;
+    ain->gt[oa.cml + d] += ax.gt;
+    ain->gq[oa.cml + d] += ax.gq;
+    ain->gl[oa.cml + d] += ax.gl;
+    ain->gi[oa.cml + d] += ax.gi;
+    ain->supsat[oa.full + d] = ax.supsat;
+    if (!last) ain->lu[oa.full + d1] += ax.lu_k1;
     surf_acc += ax.paph_surf;
     if (last) {
       surf_acc += ax.paph_k1;
     } else {
-      ain.paph[oa.half + d1] += ax.paph_k1 + paph_pending;
+      ain->paph[oa.half + d1] += ax.paph_k1 + paph_pending;
     }
     paph_pending = ax.paph_k;
 
     // output adjoints are consumed (cloudsc2ad.F90:917-919,955-966,1173,1572)
-    aout.tent[oa.loc + d] = 0.0;
-    aout.tenq[oa.loc + d] = 0.0;
-    aout.tenl[oa.loc + d] = 0.0;
-    aout.teni[oa.loc + d] = 0.0;
-    aout.clc[oa.full + d] = 0.0;
-    aout.covptot[oa.full + d] = 0.0;
-    aout.fplsl[oa.half + d1] = 0.0;
-    aout.fplsn[oa.half + d1] = 0.0;
-    aout.fhpsl[oa.half + d1] = 0.0;
-    aout.fhpsn[oa.half + d1] = 0.0;
+    aout->tent[oa.loc + d] = 0.0;
+    aout->tenq[oa.loc + d] = 0.0;
+    aout->tenl[oa.loc + d] = 0.0;
+    aout->teni[oa.loc + d] = 0.0;
+    aout->clc[oa.full + d] = 0.0;
+    aout->covptot[oa.full + d] = 0.0;
+    aout->fplsl[oa.half + d1] = 0.0;
+    aout->fplsn[oa.half + d1] = 0.0;
+    aout->fhpsl[oa.half + d1] = 0.0;
+    aout->fhpsn[oa.half + d1] = 0.0;
   }
-  ain.paph[oa.half] += paph_pending;
-  ain.paph[oa.half + (long long)g.nlev * g.nproma] += surf_acc;
+  ain = &a->ain; aout = &a->aout;
+  ain->paph[oa.half] += paph_pending;
+  ain->paph[oa.half + (long long)nlev * nproma] += surf_acc;
   // the adjoint of the (constant zero) top fluxes is discarded (cloudsc2ad.F90:1678-1679,917-919)
-  aout.fplsl[oa.half] = 0.0;
-  aout.fplsn[oa.half] = 0.0;
-  aout.fhpsl[oa.half] = 0.0;
-  aout.fhpsn[oa.half] = 0.0;
+  aout->fplsl[oa.half] = 0.0;
+  aout->fplsn[oa.half] = 0.0;
+  aout->fhpsl[oa.half] = 0.0;
+  aout->fhpsn[oa.half] = 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // Adjoint-test norms per column (cloudsc_driver_ad_mod.F90:184-195,240-264)
 // ---------------------------------------------------------------------------------------------------------
 // norm1 = <y,y>, field by field like the reference's SUMs (:185-194)
-C2_HD double adjoint_norm1_column(const Geom& g, const LaneOff& oa, const OutPtrs& y) {
+C2_HD double adjoint_norm1_column(int nlev, int nproma, const LaneOff& oa, const OutPtrs& y) {
   double st = 0, sq = 0, sl = 0, si = 0, sc = 0, sfl = 0, sfn = 0, shl = 0, shn = 0, scv = 0;
-  for (int jk = 0; jk < g.nlev; ++jk) {
-    long long d = (long long)jk * g.nproma;
+  for (int jk = 0; jk < nlev; ++jk) {
+    long long d = (long long)jk * nproma;
     double v;
     v = y.tent[oa.loc + d]; st += v * v;
     v = y.tenq[oa.loc + d]; sq += v * v;
@@ -434,8 +518,8 @@ C2_HD double adjoint_norm1_column(const Geom& g, const LaneOff& oa, const OutPtr
     v = y.clc[oa.full + d]; sc += v * v;
     v = y.covptot[oa.full + d]; scv += v * v;
   }
-  for (int jk = 0; jk <= g.nlev; ++jk) {
-    long long d = (long long)jk * g.nproma;
+  for (int jk = 0; jk <= nlev; ++jk) {
+    long long d = (long long)jk * nproma;
     double v;
     v = y.fplsl[oa.half + d]; sfl += v * v;
     v = y.fplsn[oa.half + d]; sfn += v * v;
@@ -446,16 +530,16 @@ C2_HD double adjoint_norm1_column(const Geom& g, const LaneOff& oa, const OutPtr
 }
 
 // norm2 = <x0, x_adj> with x0 = 0.01 * trajectory inputs; ZSUPSAT0 = 0 (:139,157) so that term vanishes
-C2_HD double adjoint_norm2_column(const Geom& g, const LaneOff& o, const LaneOff& oa, long long oq, const InPtrs& in,
+C2_HD double adjoint_norm2_column(int nlev, int nproma, const LaneOff& o, const LaneOff& oa, long long oq, const InPtrs& in,
                                   const double* qsat, const InPtrs& xa) {
   double s_aph = 0, s_ap = 0, s_q = 0, s_qs = 0, s_t = 0, s_l = 0, s_i = 0, s_lude = 0, s_lu = 0, s_mfu = 0, s_mfd = 0, s_gt = 0,
          s_gq = 0, s_gl = 0, s_gi = 0;
-  for (int jk = 0; jk <= g.nlev; ++jk) {
-    long long d = (long long)jk * g.nproma;
+  for (int jk = 0; jk <= nlev; ++jk) {
+    long long d = (long long)jk * nproma;
     s_aph += (in.paph[o.half + d] * 0.01) * xa.paph[oa.half + d];
   }
-  for (int jk = 0; jk < g.nlev; ++jk) {
-    long long d = (long long)jk * g.nproma;
+  for (int jk = 0; jk < nlev; ++jk) {
+    long long d = (long long)jk * nproma;
     s_ap += (in.pap[o.full + d] * 0.01) * xa.pap[oa.full + d];
     s_q += (in.q[o.full + d] * 0.01) * xa.q[oa.full + d];
     s_qs += (qsat[oq + d] * 0.01) * xa.qsat[oa.full + d];

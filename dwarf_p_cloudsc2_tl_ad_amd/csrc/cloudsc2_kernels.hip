@@ -11,6 +11,8 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -26,6 +28,13 @@ namespace {
 // error handling
 // ---------------------------------------------------------------------------------------------------------
 thread_local std::string g_err;
+
+// 0 = fast math (shared reciprocals, branch-free exp), 1 = precise (IEEE division, libm exp/tanh, reference order)
+int initial_math_mode() {
+  const char* e = getenv("CLOUDSC2_MATH");
+  return (e && (!strcmp(e, "precise") || !strcmp(e, "1"))) ? 1 : 0;
+}
+std::atomic<int> g_precise{initial_math_mode()};
 
 int fail(int code, const char* msg) {
   g_err = msg;
@@ -75,8 +84,12 @@ Consts make_consts(const cloudsc2_params& p, double ptsphy) {
   c.zlcrit_l = c.evap ? 1.9 * p.rclcrit : p.rclcrit * 2.0;
   c.zlcrit_i = c.evap ? 1.e-04 : p.rclcrit * 2.0;
   c.rcpd_r = 1.0 / p.rcpd;
+  c.zlcrit_l_r = 1.0 / c.zlcrit_l;
+  c.zlcrit_i_r = 1.0 / c.zlcrit_i;
+  c.zcons2_r = ptsphy * p.rg;
   c.rvtmp2_zero = (p.rvtmp2 == 0.0) ? 1 : 0;
   c.zzz0 = 1.0 / (p.rcpd + p.rcpd * p.rvtmp2 * 0.0);
+  c.zlfdcp0_r = 1.0 / (p.rlmlt * c.zzz0);
   c.lregcl = p.lregcl ? 1 : 0;
   c.nlev = p.nlev;
   return c;
@@ -129,41 +142,56 @@ int get_tables(const cloudsc2_params& p, const LevelTab** dev, int* kb0, int* kb
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// kernels: thin wrappers around the per-column functions of cloudsc2_column.hpp
+// kernels: thin wrappers around the per-column functions of cloudsc2_column.hpp.  Every kernel has ONE by-value
+// argument block; the device code reads it in place from the kernel-argument segment (scalar cache).
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kBlock = 128;
 
 __device__ __forceinline__ long long global_column() { return (long long)blockIdx.x * blockDim.x + threadIdx.x; }
 
-__global__ void __launch_bounds__(kBlock) satur_kernel(Consts c, Geom g, Strides s, const double* pap, const double* t,
-                                                       double* qsat) {
-  satur_column(global_column(), c, g, s, pap, t, qsat);
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class T>
+__device__ __forceinline__ const C2_CONST_AS T* kernarg() {
+  return (const C2_CONST_AS T*)__builtin_amdgcn_kernarg_segment_ptr();
+}
+#define C2_KERNEL_BODY(call) call
+#else
+#define C2_KERNEL_BODY(call)
+#endif
+
+template <bool P>
+__global__ void __launch_bounds__(kBlock) satur_kernel(SaturArgs args) {
+  C2_KERNEL_BODY(satur_column<P>(global_column(), kernarg<SaturArgs>()));
 }
 
-template <bool HAS_QSAT, bool PERT>
-__global__ void __launch_bounds__(kBlock)
-nl_kernel(Consts c, const LevelTab* __restrict__ tab, Geom g, Strides s, InPtrs in, OutPtrs out, double* zero_plane,
-          long long zero_stride, real_t lam) {
-  nl_column<HAS_QSAT, PERT>(global_column(), c, tab, g, s, in, out, zero_plane, zero_stride, lam);
+template <bool HAS_QSAT, bool PERT, bool P>
+__global__ void __launch_bounds__(kBlock) nl_kernel(NlArgs args) {
+  C2_KERNEL_BODY((nl_column<HAS_QSAT, PERT, P>(global_column(), kernarg<NlArgs>())));
 }
 
-template <bool HAS_QSAT>
-__global__ void __launch_bounds__(kBlock)
-tl_kernel(Consts c, const LevelTab* __restrict__ tab, Geom g, Strides s, Strides sp, InPtrs in, OutPtrs out, InPtrs din,
-          OutPtrs dout) {
-  tl_column<HAS_QSAT>(global_column(), c, tab, g, s, sp, in, out, din, dout);
+template <bool HAS_QSAT, bool P>
+__global__ void __launch_bounds__(kBlock) tl_kernel(TlArgs args) {
+  C2_KERNEL_BODY((tl_column<HAS_QSAT, P>(global_column(), kernarg<TlArgs>())));
 }
 
-template <bool HAS_QSAT>
-__global__ void __launch_bounds__(kBlock)
-ad_kernel(Consts c, const LevelTab* __restrict__ tab, Geom g, Strides s, Strides sa, InPtrs in, OutPtrs out, InPtrsRW ain,
-          OutPtrs aout, double* __restrict__ scratch) {
-  ad_column<HAS_QSAT>(global_column(), c, tab, g, s, sa, in, out, ain, aout, scratch);
+template <bool HAS_QSAT, bool P>
+__global__ void __launch_bounds__(kBlock) ad_kernel(AdArgs args) {
+  C2_KERNEL_BODY((ad_column<HAS_QSAT, P>(global_column(), kernarg<AdArgs>())));
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // Test-norm kernels
 // ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool lane_setup_v(const Geom& g, const Strides& s, long long gcol, LaneOff& o, bool& active) {
+  if (gcol >= g.ncols_pad) return false;
+  long long ibl = gcol / g.nproma;
+  long long jl = gcol - ibl * g.nproma;
+  o.full = ibl * s.full + jl; o.half = ibl * s.half + jl; o.cml = ibl * s.cml + jl; o.clv = ibl * s.clv + jl;
+  o.loc = ibl * s.loc + jl;
+  active = gcol < g.ngptot;
+  return true;
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -224,8 +252,8 @@ __device__ __forceinline__ void atomic_max_pos(double* addr, double v) {
 __global__ void __launch_bounds__(kBlock) adjoint_norm1_kernel(Geom g, Strides sa, OutPtrs y, double* norms) {
   long long gcol = global_column();
   LaneOff oa; bool active;
-  if (!lane_setup(g, sa, gcol, oa, active) || !active) return;
-  norms[gcol] = adjoint_norm1_column(g, oa, y);
+  if (!lane_setup_v(g, sa, gcol, oa, active) || !active) return;
+  norms[gcol] = adjoint_norm1_column(g.nlev, g.nproma, oa, y);
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -234,10 +262,10 @@ adjoint_norm2_kernel(Geom g, Strides s, Strides sa, InPtrs in, const double* qsa
   long long gcol = global_column();
   LaneOff o, oa; bool active;
   double n3 = 0.0;
-  if (lane_setup(g, s, gcol, o, active) && active) {
-    lane_setup(g, sa, gcol, oa, active);
+  if (lane_setup_v(g, s, gcol, o, active) && active) {
+    lane_setup_v(g, sa, gcol, oa, active);
     const long long oq = (gcol / g.nproma) * qsat_stride + (gcol % g.nproma);
-    double n2 = adjoint_norm2_column(g, o, oa, oq, in, qsat, xa);
+    double n2 = adjoint_norm2_column(g.nlev, g.nproma, o, oa, oq, in, qsat, xa);
     double n1 = norms[gcol];
     n3 = adjoint_norm3(n1, n2);
     norms[ncols_pad + gcol] = n2;
@@ -332,6 +360,9 @@ const char* cloudsc2_last_error(void) { return g_err.c_str(); }
 
 int cloudsc2_device_available(void) { return device_ok() ? 1 : 0; }
 
+void cloudsc2_set_math_mode(int precise) { g_precise.store(precise ? 1 : 0); }
+int cloudsc2_get_math_mode(void) { return g_precise.load(); }
+
 void cloudsc2_params_default(cloudsc2_params* p) {
   memset(p, 0, sizeof(*p));
   // standard IFS values; only RLSTT is confirmed by config-files/reference.h5
@@ -381,10 +412,13 @@ int cloudsc2_satur_launch(const cloudsc2_params* prm, int nproma, int nlev, int 
   if (!pap.ptr || !t.ptr || !qsat.ptr) return fail(CLOUDSC2_EINVAL, "NULL field");
   if (pap.block_stride != t.block_stride || pap.block_stride != qsat.block_stride)
     return fail(CLOUDSC2_EINVAL, "pap, t, qsat must share one block stride");
-  Strides s = {pap.block_stride, 0, 0, 0, 0};
-  Consts c = make_consts(*prm, 1.0);
-  hipLaunchKernelGGL(satur_kernel, dim3(grid_for(g.ncols_pad, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, c, g, s,
-                     (const double*)pap.ptr, (const double*)t.ptr, qsat.ptr);
+  SaturArgs args;
+  args.c = make_consts(*prm, 1.0);
+  args.g = g;
+  args.s = Strides{pap.block_stride, 0, 0, 0, 0};
+  args.pap = pap.ptr; args.t = t.ptr; args.qsat = qsat.ptr;
+  if (g_precise.load()) hipLaunchKernelGGL(satur_kernel<true>, dim3(grid_for(g.ncols_pad, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, args);
+  else hipLaunchKernelGGL(satur_kernel<false>, dim3(grid_for(g.ncols_pad, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, args);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -402,14 +436,20 @@ int cloudsc2_nl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
   if ((rc = resolve_out(*out, false, s, op))) return rc;
   const LevelTab* tab;
   if ((rc = get_tables(*prm, &tab, &g.kb0, &g.kb1))) return rc;
-  Consts c = make_consts(*prm, ptsphy);
+  NlArgs args;
+  args.c = make_consts(*prm, ptsphy);
+  args.g = g; args.s = s; args.in = ip; args.out = op; args.tab = tab;
+  args.zero_plane = zero_plane.ptr; args.zero_stride = zero_plane.block_stride; args.lam = pert_lambda;
   dim3 grid(grid_for(g.ncols_pad, kBlock)), block(kBlock);
   hipStream_t st = (hipStream_t)stream;
   const bool has_qsat = in->qsat.ptr != nullptr;
   const bool pertb = pert_lambda != 0.0;
-#define C2_NL(HQ, PT)                                                                                          \
-  hipLaunchKernelGGL((nl_kernel<HQ, PT>), grid, block, 0, st, c, tab, g, s, ip, op, zero_plane.ptr,            \
-                     zero_plane.block_stride, pert_lambda)
+  const bool precise = g_precise.load() != 0;
+#define C2_NL(HQ, PT)                                                                \
+  do {                                                                               \
+    if (precise) hipLaunchKernelGGL((nl_kernel<HQ, PT, true>), grid, block, 0, st, args);  \
+    else hipLaunchKernelGGL((nl_kernel<HQ, PT, false>), grid, block, 0, st, args);   \
+  } while (0)
   if (has_qsat && pertb) C2_NL(true, true);
   else if (has_qsat) C2_NL(true, false);
   else if (pertb) C2_NL(false, true);
@@ -434,11 +474,19 @@ int cloudsc2_tl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
   if ((rc = resolve_out(*pert_out, true, sp, dop))) return rc;
   const LevelTab* tab;
   if ((rc = get_tables(*prm, &tab, &g.kb0, &g.kb1))) return rc;
-  Consts c = make_consts(*prm, ptsphy);
+  TlArgs args;
+  args.c = make_consts(*prm, ptsphy);
+  args.g = g; args.s = s; args.sp = sp; args.in = ip; args.out = op; args.din = dip; args.dout = dop; args.tab = tab;
   dim3 grid(grid_for(g.ncols_pad, kBlock)), block(kBlock);
   hipStream_t st = (hipStream_t)stream;
-  if (traj_in->qsat.ptr) hipLaunchKernelGGL((tl_kernel<true>), grid, block, 0, st, c, tab, g, s, sp, ip, op, dip, dop);
-  else hipLaunchKernelGGL((tl_kernel<false>), grid, block, 0, st, c, tab, g, s, sp, ip, op, dip, dop);
+  const bool precise = g_precise.load() != 0;
+  if (traj_in->qsat.ptr) {
+    if (precise) hipLaunchKernelGGL((tl_kernel<true, true>), grid, block, 0, st, args);
+    else hipLaunchKernelGGL((tl_kernel<true, false>), grid, block, 0, st, args);
+  } else {
+    if (precise) hipLaunchKernelGGL((tl_kernel<false, true>), grid, block, 0, st, args);
+    else hipLaunchKernelGGL((tl_kernel<false, false>), grid, block, 0, st, args);
+  }
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -464,11 +512,20 @@ int cloudsc2_ad_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
   aip.gq = adj_in->gtenq.ptr; aip.gl = adj_in->gtenl.ptr; aip.gi = adj_in->gteni.ptr; aip.supsat = adj_in->supsat.ptr;
   const LevelTab* tab;
   if ((rc = get_tables(*prm, &tab, &g.kb0, &g.kb1))) return rc;
-  Consts c = make_consts(*prm, ptsphy);
+  AdArgs args;
+  args.c = make_consts(*prm, ptsphy);
+  args.g = g; args.s = s; args.sa = sa; args.in = ip; args.out = op; args.ain = aip; args.aout = aop; args.tab = tab;
+  args.scratch = scratch;
   dim3 grid(grid_for(g.ncols_pad, kBlock)), block(kBlock);
   hipStream_t st = (hipStream_t)stream;
-  if (traj_in->qsat.ptr) hipLaunchKernelGGL((ad_kernel<true>), grid, block, 0, st, c, tab, g, s, sa, ip, op, aip, aop, scratch);
-  else hipLaunchKernelGGL((ad_kernel<false>), grid, block, 0, st, c, tab, g, s, sa, ip, op, aip, aop, scratch);
+  const bool precise = g_precise.load() != 0;
+  if (traj_in->qsat.ptr) {
+    if (precise) hipLaunchKernelGGL((ad_kernel<true, true>), grid, block, 0, st, args);
+    else hipLaunchKernelGGL((ad_kernel<true, false>), grid, block, 0, st, args);
+  } else {
+    if (precise) hipLaunchKernelGGL((ad_kernel<false, true>), grid, block, 0, st, args);
+    else hipLaunchKernelGGL((ad_kernel<false, false>), grid, block, 0, st, args);
+  }
   HIP_TRY(hipGetLastError());
   return 0;
 }

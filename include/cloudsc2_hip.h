@@ -58,6 +58,14 @@ const char* cloudsc2_last_error(void);
 /* 1 if a HIP device is usable by this process, else 0. */
 int cloudsc2_device_available(void);
 
+/* Arithmetic of the kernels (process-wide; initial value from the environment variable CLOUDSC2_MATH=fast|precise).
+ *   0 fast (default): quotients on shared / batch-inverted v_rcp_f64 reciprocals refined by two Newton steps, a
+ *     branch-free exp, tanh from one exp -- a few ulp from the correctly rounded values;
+ *   1 precise: the reference's own operation order with IEEE division and libm exp/tanh/cosh.
+ * cloudsc2_tl_taylor_run always evaluates in precise mode: its verdict is decided by round-off noise. */
+void cloudsc2_set_math_mode(int precise);
+int cloudsc2_get_math_mode(void);
+
 /* ------------------------------------------------------------------------------------------------
  * Kernel level: DEVICE pointers, asynchronous on `stream` (a hipStream_t, NULL = default stream).
  * One field = base pointer + stride between NPROMA blocks (in doubles); level stride is NPROMA,

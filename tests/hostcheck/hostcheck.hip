@@ -33,8 +33,12 @@ static Consts hc_consts(const cloudsc2_params& p, double ptsphy) {
   c.zlcrit_l = c.evap ? 1.9 * p.rclcrit : p.rclcrit * 2.0;
   c.zlcrit_i = c.evap ? 1.e-04 : p.rclcrit * 2.0;
   c.rcpd_r = 1.0 / p.rcpd;
+  c.zlcrit_l_r = 1.0 / c.zlcrit_l;
+  c.zlcrit_i_r = 1.0 / c.zlcrit_i;
+  c.zcons2_r = ptsphy * p.rg;
   c.rvtmp2_zero = (p.rvtmp2 == 0.0) ? 1 : 0;
   c.zzz0 = 1.0 / (p.rcpd + p.rcpd * p.rvtmp2 * 0.0);
+  c.zlfdcp0_r = 1.0 / (p.rlmlt * c.zzz0);
   c.lregcl = p.lregcl ? 1 : 0;
   c.nlev = p.nlev;
   return c;
@@ -74,63 +78,84 @@ static Geom hc_geom(int nproma, int nlev, int ngptot) {
   return g;
 }
 
+static int g_hc_precise = 0;
+
 extern "C" {
+
+void hostcheck_set_precise(int p) { g_hc_precise = p; }
 
 int hostcheck_satur(const cloudsc2_params* prm, int nproma, int nlev, int ngptot, cloudsc2_field pap, cloudsc2_field t,
                     cloudsc2_field qsat) {
-  Geom g = hc_geom(nproma, nlev, ngptot);
-  Consts c = hc_consts(*prm, 1.0);
-  Strides s = {pap.block_stride, 0, 0, 0, 0};
-  for (long long gc = 0; gc < g.ncols_pad; ++gc) satur_column(gc, c, g, s, pap.ptr, t.ptr, qsat.ptr);
+  SaturArgs a;
+  a.g = hc_geom(nproma, nlev, ngptot);
+  a.c = hc_consts(*prm, 1.0);
+  a.s = Strides{pap.block_stride, 0, 0, 0, 0};
+  a.pap = pap.ptr; a.t = t.ptr; a.qsat = qsat.ptr;
+  for (long long gc = 0; gc < a.g.ncols_pad; ++gc) { if (g_hc_precise) satur_column<true>(gc, &a); else satur_column<false>(gc, &a); }
   return 0;
 }
 
 int hostcheck_nl(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot, const cloudsc2_inputs* in,
                  const cloudsc2_outputs* out, cloudsc2_field zero_plane, double lam) {
-  Geom g = hc_geom(nproma, nlev, ngptot);
-  Consts c = hc_consts(*prm, ptsphy);
-  LevelTab tab; hc_tables(*prm, tab, g);
-  Strides s = {0, 0, 0, 0, 0}; InPtrs ip; OutPtrs op;
-  hc_in(*in, s, ip); hc_out(*out, s, op);
+  NlArgs a;
+  a.g = hc_geom(nproma, nlev, ngptot);
+  a.c = hc_consts(*prm, ptsphy);
+  LevelTab tab; hc_tables(*prm, tab, a.g);
+  a.tab = &tab;
+  a.s = Strides{0, 0, 0, 0, 0};
+  hc_in(*in, a.s, a.in); hc_out(*out, a.s, a.out);
+  a.zero_plane = zero_plane.ptr; a.zero_stride = zero_plane.block_stride; a.lam = lam;
   const bool hq = in->qsat.ptr != nullptr, pt = lam != 0.0;
-  for (long long gc = 0; gc < g.ncols_pad; ++gc) {
-    if (hq && pt) nl_column<true, true>(gc, c, &tab, g, s, ip, op, zero_plane.ptr, zero_plane.block_stride, lam);
-    else if (hq) nl_column<true, false>(gc, c, &tab, g, s, ip, op, zero_plane.ptr, zero_plane.block_stride, lam);
-    else if (pt) nl_column<false, true>(gc, c, &tab, g, s, ip, op, zero_plane.ptr, zero_plane.block_stride, lam);
-    else nl_column<false, false>(gc, c, &tab, g, s, ip, op, zero_plane.ptr, zero_plane.block_stride, lam);
+  for (long long gc = 0; gc < a.g.ncols_pad; ++gc) {
+    if (g_hc_precise) {
+      if (hq && pt) nl_column<true, true, true>(gc, &a);
+      else if (hq) nl_column<true, false, true>(gc, &a);
+      else if (pt) nl_column<false, true, true>(gc, &a);
+      else nl_column<false, false, true>(gc, &a);
+    } else {
+      if (hq && pt) nl_column<true, true, false>(gc, &a);
+      else if (hq) nl_column<true, false, false>(gc, &a);
+      else if (pt) nl_column<false, true, false>(gc, &a);
+      else nl_column<false, false, false>(gc, &a);
+    }
   }
   return 0;
 }
 
 int hostcheck_tl(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot, const cloudsc2_inputs* in,
                  const cloudsc2_outputs* out, const cloudsc2_inputs* din, const cloudsc2_outputs* dout) {
-  Geom g = hc_geom(nproma, nlev, ngptot);
-  Consts c = hc_consts(*prm, ptsphy);
-  LevelTab tab; hc_tables(*prm, tab, g);
-  Strides s = {0, 0, 0, 0, 0}, sp = {0, 0, 0, 0, 0}; InPtrs ip, dip; OutPtrs op, dop;
-  hc_in(*in, s, ip); hc_out(*out, s, op); hc_in(*din, sp, dip); hc_out(*dout, sp, dop);
-  for (long long gc = 0; gc < g.ncols_pad; ++gc) {
-    if (in->qsat.ptr) tl_column<true>(gc, c, &tab, g, s, sp, ip, op, dip, dop);
-    else tl_column<false>(gc, c, &tab, g, s, sp, ip, op, dip, dop);
+  TlArgs a;
+  a.g = hc_geom(nproma, nlev, ngptot);
+  a.c = hc_consts(*prm, ptsphy);
+  LevelTab tab; hc_tables(*prm, tab, a.g);
+  a.tab = &tab;
+  a.s = Strides{0, 0, 0, 0, 0}; a.sp = Strides{0, 0, 0, 0, 0};
+  hc_in(*in, a.s, a.in); hc_out(*out, a.s, a.out); hc_in(*din, a.sp, a.din); hc_out(*dout, a.sp, a.dout);
+  for (long long gc = 0; gc < a.g.ncols_pad; ++gc) {
+    if (g_hc_precise) { if (in->qsat.ptr) tl_column<true, true>(gc, &a); else tl_column<false, true>(gc, &a); }
+    else { if (in->qsat.ptr) tl_column<true, false>(gc, &a); else tl_column<false, false>(gc, &a); }
   }
   return 0;
 }
 
 int hostcheck_ad(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot, const cloudsc2_inputs* in,
                  const cloudsc2_outputs* out, const cloudsc2_inputs* ain, const cloudsc2_outputs* aout, double* scratch) {
-  Geom g = hc_geom(nproma, nlev, ngptot);
-  Consts c = hc_consts(*prm, ptsphy);
-  LevelTab tab; hc_tables(*prm, tab, g);
-  Strides s = {0, 0, 0, 0, 0}, sa = {0, 0, 0, 0, 0}; InPtrs ip, aip_c; OutPtrs op, aop;
-  hc_in(*in, s, ip); hc_out(*out, s, op); hc_in(*ain, sa, aip_c); hc_out(*aout, sa, aop);
-  InPtrsRW aip;
-  aip.paph = ain->paph.ptr; aip.pap = ain->pap.ptr; aip.q = ain->q.ptr; aip.qsat = ain->qsat.ptr; aip.t = ain->t.ptr;
-  aip.l = ain->l.ptr; aip.i = ain->i.ptr; aip.lude = ain->lude.ptr; aip.lu = ain->lu.ptr; aip.mfu = ain->mfu.ptr;
-  aip.mfd = ain->mfd.ptr; aip.gt = ain->gtent.ptr; aip.gq = ain->gtenq.ptr; aip.gl = ain->gtenl.ptr; aip.gi = ain->gteni.ptr;
-  aip.supsat = ain->supsat.ptr;
-  for (long long gc = 0; gc < g.ncols_pad; ++gc) {
-    if (in->qsat.ptr) ad_column<true>(gc, c, &tab, g, s, sa, ip, op, aip, aop, scratch);
-    else ad_column<false>(gc, c, &tab, g, s, sa, ip, op, aip, aop, scratch);
+  AdArgs a;
+  a.g = hc_geom(nproma, nlev, ngptot);
+  a.c = hc_consts(*prm, ptsphy);
+  LevelTab tab; hc_tables(*prm, tab, a.g);
+  a.tab = &tab;
+  a.s = Strides{0, 0, 0, 0, 0}; a.sa = Strides{0, 0, 0, 0, 0};
+  InPtrs aip_c;
+  hc_in(*in, a.s, a.in); hc_out(*out, a.s, a.out); hc_in(*ain, a.sa, aip_c); hc_out(*aout, a.sa, a.aout);
+  a.ain.paph = ain->paph.ptr; a.ain.pap = ain->pap.ptr; a.ain.q = ain->q.ptr; a.ain.qsat = ain->qsat.ptr; a.ain.t = ain->t.ptr;
+  a.ain.l = ain->l.ptr; a.ain.i = ain->i.ptr; a.ain.lude = ain->lude.ptr; a.ain.lu = ain->lu.ptr; a.ain.mfu = ain->mfu.ptr;
+  a.ain.mfd = ain->mfd.ptr; a.ain.gt = ain->gtent.ptr; a.ain.gq = ain->gtenq.ptr; a.ain.gl = ain->gtenl.ptr;
+  a.ain.gi = ain->gteni.ptr; a.ain.supsat = ain->supsat.ptr;
+  a.scratch = scratch;
+  for (long long gc = 0; gc < a.g.ncols_pad; ++gc) {
+    if (g_hc_precise) { if (in->qsat.ptr) ad_column<true, true>(gc, &a); else ad_column<false, true>(gc, &a); }
+    else { if (in->qsat.ptr) ad_column<true, false>(gc, &a); else ad_column<false, false>(gc, &a); }
   }
   return 0;
 }

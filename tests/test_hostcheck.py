@@ -21,6 +21,15 @@ def oracle():
     return refcall.OracleLib()
 
 
+@pytest.fixture(params=["fast", "precise"], autouse=True)
+def math_mode(request):
+    """Both arithmetic variants of the kernels: shared-reciprocal fast math (default) and the reference's own
+    operation order with IEEE division / libm exp (what the Taylor-test driver uses)."""
+    hostcheck().hostcheck_set_precise(int(request.param == "precise"))
+    yield request.param
+    hostcheck().hostcheck_set_precise(0)
+
+
 def oracle_qsat(oracle, st):
     q = np.zeros_like(st.PAP)
     for ibl in range(st.nblocks):
