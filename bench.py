@@ -161,9 +161,20 @@ def main():
 
     k_avg = float(kms.mean())
     achieved = bpc * args.ngptot / (k_avg * 1e-3) / 1e9
+    # HBM traffic from the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, calibrated as the MI355X guide
+    # prescribes; tools/pmc_workload.py + tools/pmc_parse.py), scaled per column to this launch.  null if not measured.
+    traffic = None
+    pmc_files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("pmc_traffic.json")) \
+        if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+    if pmc_files:
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_files[-1])))
+            traffic = pmc["kernels"][args.kernel]["traffic_bytes"] / pmc["ngptot"] * args.ngptot
+        except (KeyError, ValueError, OSError):
+            traffic = None
     roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_column": bpc,
-                "kernel_ms_avg": k_avg, "kernel_ms_min": float(kms.min())}
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_column": bpc,
+                "algorithmic_bytes": bpc * args.ngptot, "kernel_ms_avg": k_avg, "kernel_ms_min": float(kms.min())}
 
     out = {
         "metric": f"CLOUDSC2 {args.kernel.upper()} columns/sec (fp64, NLEV=137)", "value": value, "unit": "columns/s",
@@ -179,6 +190,15 @@ def main():
         cb = cpu_baseline(tab, prm, 32, args.ngptot)
         if cb:
             out["cpu_baseline"] = cb
+    if world > 1:
+        # the only inter-GPU exchange of the path: max-reduce the self-test verdict norms over RCCL (outside the timing)
+        try:
+            vt = c2.state_from_table(tab, 64, 1024, col0=rank * 1024)
+            zad, _, _ = c2.run_state(c2.default_params(c2.ceta_from_table(tab), lregcl=True), vt, "ad")
+            znorm = c2dist.allreduce_max([zad], dev)
+            out["verdicts"] = {"ad_symmetry_max_eps": float(znorm[0]), "ad_ok": bool(c2.adjoint_verdict(float(znorm[0])))}
+        except Exception as e:  # noqa: BLE001
+            out["verdicts"] = {"error": repr(e)}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

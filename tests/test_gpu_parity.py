@@ -301,3 +301,45 @@ def test_invalid_arguments_fail_loudly():
     prm.lphylin = 0
     with pytest.raises(c2.Cloudsc2Error):
         c2.run_state(prm, st, "nl")
+
+
+def _run_fortran(exe, *args):
+    import os
+    import subprocess
+
+    from tests.util import ROOT
+
+    path = os.path.join(ROOT, "dwarf_p_cloudsc2_tl_ad_amd", "fortran", "build", exe)
+    if not os.path.exists(path):
+        pytest.fail(f"{path} missing: run __graft_entry__.build()")
+    r = subprocess.run([path, *map(str, args)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return r.stdout, r.stderr
+
+
+def test_fortran_drivers_through_iso_c_binding():
+    """The Fortran drivers with the reference's signatures (fortran/cloudsc_driver*_mod.F90) call the same C ABI:
+    dwarf-cloudsc2-nl must reproduce the Python driver's outputs, -tl and -ad must print the reference's verdicts
+    for the README invocations (README.md:47-62: `nl 4 160000 32`, `tl 1 100 1`, `ad 1 100 100`)."""
+    import re
+
+    out, err = _run_fortran("dwarf-cloudsc2-nl", 4, 16000, 32)
+    assert "NGPBLKS=500" in err
+    tab = c2.synthetic_table()
+    prm = c2.default_params(c2.ceta_from_table(tab))
+    st = c2.state_from_table(tab, 32, 16000)
+    c2.run_state(prm, st, "nl")
+    want = {"PFPLSN": st.PFPLSN, "PFHPSN": st.PFHPSN, "PFPLSL": st.PFPLSL, "PA": st.PA, "TENDENCY_T": st.B_LOC[:, 0],
+            "TENDENCY_Q": st.B_LOC[:, 2], "TENDENCY_L": st.B_LOC[:, 3], "TENDENCY_I": st.B_LOC[:, 4]}
+    for name, a in want.items():
+        m = re.search(rf"^\s*{name}\s+(\S+)\s+(\S+)\s+(\S+)\s*$", out, flags=re.M)
+        assert m, (name, out)
+        mn, mx, s = map(float, m.groups())
+        assert abs(mn - a.min()) <= 1e-12 * max(1e-300, np.abs(a).max())
+        assert abs(mx - a.max()) <= 1e-12 * max(1e-300, np.abs(a).max())
+        assert abs(s - np.abs(a).sum()) <= 1e-11 * np.abs(a).sum()
+
+    out, _ = _run_fortran("dwarf-cloudsc2-tl", 1, 100, 1)
+    assert "TEST PASSED, penalty" in out, out
+    out, _ = _run_fortran("dwarf-cloudsc2-ad", 1, 100, 100)
+    assert "TEST OK" in out, out

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Turn the two rocprofv3 --pmc passes of tools/pmc_workload.py into per-launch HBM traffic.
+
+    python tools/pmc_parse.py gpurun_out/pmc_fetch gpurun_out/pmc_write NGPTOT > profiles/rNN_pmc_traffic.json
+
+FETCH_SIZE / WRITE_SIZE are in KiB (guide: hbm_bytes = (FETCH_SIZE + WRITE_SIZE) * 1024).  gfx950 under-reports wide
+coalesced reads by exactly 2x for 16 B per lane; this code reads 8 B per lane, so the read and write factors are
+calibrated on the SATUR dispatch whose byte count is known (2 planes in, 1 plane out)."""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def per_kernel(dirname, counter):
+    acc = {}
+    for f in glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row.get("Counter_Name") != counter:
+                continue
+            name = row["Kernel_Name"]
+            key = ("satur" if "satur_kernel" in name else "nl" if "nl_kernel" in name else "tl" if "tl_kernel" in name
+                   else "ad" if "ad_kernel" in name else None)
+            if key is None:
+                continue
+            acc.setdefault(key, {}).setdefault(row["Dispatch_Id"], 0.0)
+            acc[key][row["Dispatch_Id"]] += float(row["Counter_Value"])
+    return {k: sum(v.values()) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
+
+
+def main():
+    fetch_dir, write_dir, ngptot = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    nlev = 137
+    fetch, nf = per_kernel(fetch_dir, "FETCH_SIZE")
+    write, nw = per_kernel(write_dir, "WRITE_SIZE")
+    plane = ngptot * nlev * 8
+    cal_r = (2 * plane) / (fetch["satur"] * 1024)
+    cal_w = (1 * plane) / (write["satur"] * 1024)
+    algo = {"nl": 28536, "tl": 57072, "ad": 85608 + 2 * 8 * nlev}  # bytes per column, DESIGN.md
+    out = {"ngptot": ngptot, "unit": "bytes per launch", "calibration": {"kernel": "satur_kernel (8 B/lane, 2 planes in, 1 out)",
+           "read_factor": cal_r, "write_factor": cal_w, "raw_fetch_kib": fetch["satur"], "raw_write_kib": write["satur"]},
+           "dispatches": {"fetch": nf, "write": nw}, "kernels": {}}
+    for k in ("nl", "tl", "ad"):
+        if k in fetch and k in write:
+            rd = fetch[k] * 1024 * cal_r
+            wr = write[k] * 1024 * cal_w
+            out["kernels"][k] = {"read_bytes": rd, "write_bytes": wr, "traffic_bytes": rd + wr,
+                                 "algorithmic_bytes": algo[k] * ngptot, "traffic_over_algorithmic": (rd + wr) / (algo[k] * ngptot),
+                                 "raw_fetch_kib": fetch[k], "raw_write_kib": write[k]}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Workload for the rocprofv3 PMC passes (HBM traffic of the NL / TL / AD kernels).
+
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 tools/pmc_workload.py
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 tools/pmc_workload.py
+
+Each kernel is launched a few times on NGPTOT columns.  The SATUR kernel (reads 2 planes, writes 1 plane, 8 B per
+lane like every access of the physics kernels) is the calibration dispatch with a known byte count, as
+/opt/skills/guides/MI355X_MICROARCH.md (HBM section) asks for access widths other than 16 B per lane.
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import dwarf_p_cloudsc2_tl_ad_amd as c2  # noqa: E402
+
+ngptot = int(os.environ.get("PMC_NGPTOT", "1048576"))  # state >> 256 MiB Infinity Cache
+nproma = 128
+reps = 3
+tab = c2.synthetic_table()
+prm = c2.default_params(c2.ceta_from_table(tab), lregcl=True)
+st = c2.state_from_table(tab, nproma, ngptot)
+ds = c2.DeviceState(st, "cuda:0")
+for _ in range(reps):
+    ds.satur(prm)
+for _ in range(reps):
+    ds.nl(prm)
+inc = ds.increments()
+dout = c2.FlatFields("out", ds.nb, ds.nlev, ds.nproma, ds.device)
+for _ in range(reps):
+    ds.tl(prm, inc, dout)
+scratch = ds.new_scratch()
+for _ in range(reps):
+    ds.ad(prm, inc, dout, scratch)
+torch.cuda.synchronize()
+print("pmc workload done", ngptot)
