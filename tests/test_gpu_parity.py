@@ -337,7 +337,7 @@ def test_fortran_drivers_through_iso_c_binding():
         mn, mx, s = map(float, m.groups())
         assert abs(mn - a.min()) <= 1e-12 * max(1e-300, np.abs(a).max())
         assert abs(mx - a.max()) <= 1e-12 * max(1e-300, np.abs(a).max())
-        assert abs(s - np.abs(a).sum()) <= 1e-11 * np.abs(a).sum()
+        assert abs(s - np.abs(a).sum()) <= 1e-9 * np.abs(a).sum()  # Fortran SUM is sequential over 2e6 terms
 
     out, _ = _run_fortran("dwarf-cloudsc2-tl", 1, 100, 1)
     assert "TEST PASSED, penalty" in out, out
