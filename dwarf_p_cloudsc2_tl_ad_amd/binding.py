@@ -15,7 +15,8 @@ CLOUDSC2_MAX_NLEV = 200
 CLOUDSC2_EINVAL, CLOUDSC2_ENODEVICE, CLOUDSC2_ETLWRONG = -1, -2, -3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libcloudsc2_hip.so")
+# CLOUDSC2_LIB: load another build of the same library (kernel-tuning experiments)
+LIB_PATH = os.environ.get("CLOUDSC2_LIB") or os.path.join(_HERE, "csrc", "libcloudsc2_hip.so")
 
 
 class Cloudsc2Error(RuntimeError):

@@ -17,8 +17,7 @@ namespace cloudsc2 {
 
 // per-level, column-independent tables (device copy)
 struct LevelTab {
-  double ceta[CLOUDSC2_MAX_NLEV];
-  double zscalm[CLOUDSC2_MAX_NLEV];
+  struct { double ceta, zscalm; } lev[CLOUDSC2_MAX_NLEV];  // interleaved: one 16-byte scalar load per level
 };
 
 struct Geom {
@@ -84,51 +83,51 @@ C2_HD bool lane_setup(GeomP g, StridesP s, long long gcol, LaneOff& o, bool& act
   return true;
 }
 
-// One level's worth of raw input planes at level jk.
+// Everything level jk needs from the input planes EXCEPT PAPHP1(JK), which is the previous level's PAPHP1(JK+1):
+// the 14 full-level planes at jk plus the two look-ahead values PAPHP1(JK+1) and PLU(JK+1) (cloudsc2.F90:272,435).
+// Loading the look-ahead values together with the level they belong to lets the whole set be requested one full
+// level ahead of its use.
 struct RawLevel {
-  real_t paph, pap, q, qsat, t, l, i, lude, lu, mfu, mfd, gt, gq, gl, gi, supsat;
+  real_t paph_k1, pap, q, qsat, t, l, i, lude, lu_k1, mfu, mfd, gt, gq, gl, gi, supsat;
 };
 
 template <bool HAS_QSAT>
-C2_HD void load_raw(InPtrsP p, const LaneOff& o, int nproma, int jk, bool full_level, RawLevel& r) {
+C2_HD void load_level(InPtrsP pp, const LaneOff& o, int nproma, int nlev, int jk, RawLevel& r) {
+  const InPtrs p = *pp;
   const long long d = (long long)jk * nproma;
-  r.paph = p->paph[o.half + d];
-  if (full_level) {
-    r.pap = p->pap[o.full + d];
-    r.q = p->q[o.full + d];
-    r.t = p->t[o.full + d];
-    r.l = p->l[o.clv + d];
-    r.i = p->i[o.clv + d];
-    r.lude = p->lude[o.full + d];
-    r.lu = p->lu[o.full + d];
-    r.mfu = p->mfu[o.full + d];
-    r.mfd = p->mfd[o.full + d];
-    r.gt = p->gt[o.cml + d];
-    r.gq = p->gq[o.cml + d];
-    r.gl = p->gl[o.cml + d];
-    r.gi = p->gi[o.cml + d];
-    r.supsat = p->supsat[o.full + d];
-    if (HAS_QSAT) r.qsat = p->qsat[o.full + d];
-  }
+  r.paph_k1 = p.paph[o.half + d + nproma];
+  r.lu_k1 = (jk + 1 < nlev) ? p.lu[o.full + d + nproma] : 0.0;
+  r.pap = p.pap[o.full + d];
+  r.q = p.q[o.full + d];
+  r.t = p.t[o.full + d];
+  r.l = p.l[o.clv + d];
+  r.i = p.i[o.clv + d];
+  r.lude = p.lude[o.full + d];
+  r.mfu = p.mfu[o.full + d];
+  r.mfd = p.mfd[o.full + d];
+  r.gt = p.gt[o.cml + d];
+  r.gq = p.gq[o.cml + d];
+  r.gl = p.gl[o.cml + d];
+  r.gi = p.gi[o.cml + d];
+  r.supsat = p.supsat[o.full + d];
+  if (HAS_QSAT) r.qsat = p.qsat[o.full + d];
 }
 
 // Perturbed state of the Taylor test: x5 = x + lambda*(0.01*x) (cloudsc_driver_tl_mod.F90:156-171,200-215).
 C2_HD real_t pert(real_t x, real_t lam) { return x + lam * (x * 0.01); }
 
-C2_HD void perturb_raw(RawLevel& r, real_t lam, bool full_level) {
-  r.paph = pert(r.paph, lam);
-  if (full_level) {
-    r.pap = pert(r.pap, lam); r.q = pert(r.q, lam); r.qsat = pert(r.qsat, lam); r.t = pert(r.t, lam);
-    r.l = pert(r.l, lam); r.i = pert(r.i, lam); r.lude = pert(r.lude, lam); r.lu = pert(r.lu, lam);
-    r.mfu = pert(r.mfu, lam); r.mfd = pert(r.mfd, lam); r.gt = pert(r.gt, lam); r.gq = pert(r.gq, lam);
-    r.gl = pert(r.gl, lam); r.gi = pert(r.gi, lam); r.supsat = pert(r.supsat, lam);
-  }
+C2_HD void perturb_raw(RawLevel& r, real_t lam) {
+  r.paph_k1 = pert(r.paph_k1, lam);
+  r.pap = pert(r.pap, lam); r.q = pert(r.q, lam); r.qsat = pert(r.qsat, lam); r.t = pert(r.t, lam);
+  r.l = pert(r.l, lam); r.i = pert(r.i, lam); r.lude = pert(r.lude, lam); r.lu_k1 = pert(r.lu_k1, lam);
+  r.mfu = pert(r.mfu, lam); r.mfd = pert(r.mfd, lam); r.gt = pert(r.gt, lam); r.gq = pert(r.gq, lam);
+  r.gl = pert(r.gl, lam); r.gi = pert(r.gi, lam); r.supsat = pert(r.supsat, lam);
 }
 
-C2_HD void make_level_in(const RawLevel& cur, const RawLevel& nxt, real_t paph_surf, LevelIn& x) {
-  x.paph_k = cur.paph; x.paph_k1 = nxt.paph;
+C2_HD void make_level_in(const RawLevel& cur, real_t paph_k, real_t paph_surf, LevelIn& x) {
+  x.paph_k = paph_k; x.paph_k1 = cur.paph_k1;
   x.pap = cur.pap; x.q = cur.q; x.qs = cur.qsat; x.t = cur.t; x.l = cur.l; x.i = cur.i;
-  x.lude = cur.lude; x.lu_k1 = nxt.lu; x.mfu = cur.mfu; x.mfd = cur.mfd;
+  x.lude = cur.lude; x.lu_k1 = cur.lu_k1; x.mfu = cur.mfu; x.mfd = cur.mfd;
   x.gt = cur.gt; x.gq = cur.gq; x.gl = cur.gl; x.gi = cur.gi; x.supsat = cur.supsat;
   x.paph_surf = paph_surf;
 }
@@ -151,7 +150,7 @@ C2_HD real_t tropopause(ConstsP c, LevelTabP tab, InPtrsP p, const LaneOff& o, G
       real_t t1 = pt[o.full + d1], g1 = pg[o.cml + d1];
       if (PERT) { t1 = pert(t1, lam); g1 = pert(g1, lam); }
       real_t tdn = t1 + ptsphy * g1;
-      real_t ce = tab->ceta[jk];
+      real_t ce = tab->lev[jk].ceta;
       if (ce > 0.1 && ce < 0.4 && tup > tdn) ztrpaus = ce;
       tup = tdn;
     }
@@ -159,34 +158,36 @@ C2_HD real_t tropopause(ConstsP c, LevelTabP tab, InPtrsP p, const LaneOff& o, G
   return ztrpaus;
 }
 
-C2_HD void store_out(OutPtrsP p, const LaneOff& o, int nproma, int jk, ConstsP c, const LevelOut& v) {
+// All ten output pointers must be valid (the launchers substitute nothing: a skipped trajectory store is a
+// template flag of the TL kernel) -- no per-pointer branches, the pointer block is read with two wide scalar loads.
+C2_HD void store_out(OutPtrsP pp, const LaneOff& o, int nproma, int jk, const LevelOut& v) {
+  const OutPtrs p = *pp;
   const long long d = (long long)jk * nproma;
-  if (p->tent) p->tent[o.loc + d] = v.tent;
-  if (p->tenq) p->tenq[o.loc + d] = v.tenq;
-  if (p->tenl) p->tenl[o.loc + d] = v.tenl;
-  if (p->teni) p->teni[o.loc + d] = v.teni;
-  if (p->clc) p->clc[o.full + d] = v.clc;
-  if (p->covptot) p->covptot[o.full + d] = v.covptot;
+  p.tent[o.loc + d] = v.tent;
+  p.tenq[o.loc + d] = v.tenq;
+  p.tenl[o.loc + d] = v.tenl;
+  p.teni[o.loc + d] = v.teni;
+  p.clc[o.full + d] = v.clc;
+  p.covptot[o.full + d] = v.covptot;
   const long long d1 = d + nproma;
-  if (p->fplsl) p->fplsl[o.half + d1] = v.fplsl;
-  if (p->fplsn) p->fplsn[o.half + d1] = v.fplsn;
-  // enthalpy fluxes (cloudsc2.F90:732-733)
-  if (p->fhpsl) p->fhpsl[o.half + d1] = -v.fplsl * c->rlvtt;
-  if (p->fhpsn) p->fhpsn[o.half + d1] = -v.fplsn * c->rlstt;
+  p.fplsl[o.half + d1] = v.fplsl;
+  p.fplsn[o.half + d1] = v.fplsn;
+  p.fhpsl[o.half + d1] = v.fhpsl;
+  p.fhpsn[o.half + d1] = v.fhpsn;
 }
 
 C2_HD void store_top(OutPtrsP p, const LaneOff& o, ConstsP c) {
   // fluxes at the model top are zero (cloudsc2.F90:308-309); enthalpy fluxes -0*RLVTT (:732-733)
   const real_t z = 0.0;
-  if (p->fplsl) p->fplsl[o.half] = z;
-  if (p->fplsn) p->fplsn[o.half] = z;
-  if (p->fhpsl) p->fhpsl[o.half] = -z * c->rlvtt;
-  if (p->fhpsn) p->fhpsn[o.half] = -z * c->rlstt;
+  p->fplsl[o.half] = z;
+  p->fplsn[o.half] = z;
+  p->fhpsl[o.half] = -z * c->rlvtt;
+  p->fhpsn[o.half] = -z * c->rlstt;
 }
 
 C2_HD void level_cst(LevelTabP tab, int jk, bool last, LevelCst& k) {
-  k.ceta = tab->ceta[jk];
-  k.zscalm = tab->zscalm[jk];
+  k.ceta = tab->lev[jk].ceta;
+  k.zscalm = tab->lev[jk].zscalm;
   k.last = last;
 }
 
@@ -234,7 +235,7 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
     double* cov = a->out.covptot;
     for (int jk = 0; jk < nlev; ++jk) {
       long long d = (long long)jk * nproma;
-      if (cov) cov[o.full + d] = 0.0;
+      cov[o.full + d] = 0.0;
       if (zero_plane) zero_plane[ozero + d] = 0.0;
     }
     return;
@@ -258,31 +259,35 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
 
   Carry cy; cy.rfl = 0.0; cy.sfl = 0.0; cy.covptot = 0.0;
   RawLevel cur, nxt;
-  load_raw<HAS_QSAT>(in, o, nproma, 0, true, cur);
-  if (!HAS_QSAT) cur.qsat = satur_point<P>(c, cur.pap, cur.t);
-  if (PERT) perturb_raw(cur, lam, true);
+  real_t paph_k = in->paph[o.half];
+  if (PERT) paph_k = pert(paph_k, lam);
+  load_level<HAS_QSAT>(in, o, nproma, nlev, 0, cur);
 
   for (int jk = 0; jk < nlev; ++jk) {
     const bool last = (jk == nlev - 1);
-    C2_LAUNDER(a);
-    c = &a->c; in = &a->in; out = &a->out; tab = (LevelTabP)a->tab;
+    NlArgsP ap = a;  // field pointers are re-read from the kernel-argument segment every level (transient SGPRs);
+    C2_LAUNDER(ap);  // the physical constants stay resident
+    in = &ap->in;
+    // request everything level jk+1 needs now; nothing below touches `nxt` before the end of this level, so the
+    // HBM latency is covered by the whole level's arithmetic
     nxt = cur;
-    nxt.lu = 0.0;
-    load_raw<HAS_QSAT>(in, o, nproma, jk + 1, !last, nxt);
-    if (!last && !HAS_QSAT) nxt.qsat = satur_point<P>(c, nxt.pap, nxt.t);
-    if (PERT) perturb_raw(nxt, lam, !last);
+    if (!last) load_level<HAS_QSAT>(in, o, nproma, nlev, jk + 1, nxt);
+
+    if (!HAS_QSAT) cur.qsat = satur_point<P>(c, cur.pap, cur.t);  // SATUR on the unperturbed PAP, PT
+    if (PERT) perturb_raw(cur, lam);
 
     LevelCst k;
     level_cst(tab, jk, last, k);
     LevelIn x;
-    make_level_in(cur, nxt, paph_surf, x);
+    make_level_in(cur, paph_k, paph_surf, x);
     LevelTraj tr;
     LevelOut lo;
     level_forward<P>(c, k, rh, x, cy, tr, lo);
-    C2_LAUNDER(a);
-    out = &a->out; c = &a->c;
-    store_out(out, o, nproma, jk, c, lo);
+    C2_LAUNDER(ap);
+    out = &ap->out;
+    store_out(out, o, nproma, jk, lo);
     if (zero_plane) zero_plane[ozero + (long long)jk * nproma] = 0.0;
+    paph_k = cur.paph_k1;
     cur = nxt;
   }
 }
@@ -290,7 +295,7 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
 // ---------------------------------------------------------------------------------------------------------
 // TL: SATUR (optionally fused) + CLOUDSC2TL for one column
 // ---------------------------------------------------------------------------------------------------------
-template <bool HAS_QSAT, bool P>
+template <bool HAS_QSAT, bool P, bool STORE_TRAJ>
 C2_HD void tl_column(long long gcol, TlArgsP a) {
   LaneOff o, op; bool active;
   if (!lane_setup(&a->g, &a->s, gcol, o, active)) return;
@@ -312,41 +317,42 @@ C2_HD void tl_column(long long gcol, TlArgsP a) {
     dpaph_surf = din->paph[op.half + (long long)nlev * nproma];
   }
 
-  store_top(out, o, c);
+  if (STORE_TRAJ) store_top(out, o, c);
   store_top(dout, op, c);
 
   Carry cy; cy.rfl = 0.0; cy.sfl = 0.0; cy.covptot = 0.0;
   Carry dcy; dcy.rfl = 0.0; dcy.sfl = 0.0; dcy.covptot = 0.0;
   RawLevel cur, nxt, dcur, dnxt;
-  load_raw<HAS_QSAT>(in, o, nproma, 0, true, cur);
-  if (!HAS_QSAT) cur.qsat = satur_point<P>(c, cur.pap, cur.t);
-  load_raw<true>(din, op, nproma, 0, true, dcur);
+  real_t paph_k = in->paph[o.half], dpaph_k = din->paph[op.half];
+  load_level<HAS_QSAT>(in, o, nproma, nlev, 0, cur);
+  load_level<true>(din, op, nproma, nlev, 0, dcur);
 
   for (int jk = 0; jk < nlev; ++jk) {
     const bool last = (jk == nlev - 1);
-    C2_LAUNDER(a);
-    c = &a->c; in = &a->in; din = &a->din; tab = (LevelTabP)a->tab;
+    TlArgsP ap = a;
+    C2_LAUNDER(ap);
+    in = &ap->in; din = &ap->din;
     nxt = cur; dnxt = dcur;
-    nxt.lu = 0.0; dnxt.lu = 0.0;
-    load_raw<HAS_QSAT>(in, o, nproma, jk + 1, !last, nxt);
-    load_raw<true>(din, op, nproma, jk + 1, !last, dnxt);
-    if (!last && !HAS_QSAT) nxt.qsat = satur_point<P>(c, nxt.pap, nxt.t);
+    if (!last) {
+      load_level<HAS_QSAT>(in, o, nproma, nlev, jk + 1, nxt);
+      load_level<true>(din, op, nproma, nlev, jk + 1, dnxt);
+    }
+    if (!HAS_QSAT) cur.qsat = satur_point<P>(c, cur.pap, cur.t);
 
     LevelCst k;
     level_cst(tab, jk, last, k);
     LevelIn x, dx;
-    make_level_in(cur, nxt, paph_surf, x);
-    make_level_in(dcur, dnxt, dpaph_surf, dx);
+    make_level_in(cur, paph_k, paph_surf, x);
+    make_level_in(dcur, dpaph_k, dpaph_surf, dx);
     LevelTraj tr;
     LevelOut lo, dlo;
     level_forward<P>(c, k, rh, x, cy, tr, lo);
-    C2_LAUNDER(a);
-    c = &a->c;
     level_tl(c, k, x, tr, dx, dcy, dlo);
-    C2_LAUNDER(a);
-    c = &a->c; out = &a->out; dout = &a->dout;
-    store_out(out, o, nproma, jk, c, lo);
-    store_out(dout, op, nproma, jk, c, dlo);
+    C2_LAUNDER(ap);
+    out = &ap->out; dout = &ap->dout;
+    if (STORE_TRAJ) store_out(out, o, nproma, jk, lo);
+    store_out(dout, op, nproma, jk, dlo);
+    paph_k = cur.paph_k1; dpaph_k = dcur.paph_k1;
     cur = nxt;
     dcur = dnxt;
   }
@@ -385,27 +391,28 @@ C2_HD void ad_column(long long gcol, AdArgsP a) {
   {
     Carry cy; cy.rfl = 0.0; cy.sfl = 0.0; cy.covptot = 0.0;
     RawLevel cur, nxt;
-    load_raw<HAS_QSAT>(in, o, nproma, 0, true, cur);
-    if (!HAS_QSAT) cur.qsat = satur_point<P>(c, cur.pap, cur.t);
+    real_t paph_k = in->paph[o.half];
+    load_level<HAS_QSAT>(in, o, nproma, nlev, 0, cur);
     for (int jk = 0; jk < nlev; ++jk) {
       const bool last = (jk == nlev - 1);
-      C2_LAUNDER(a);
-      c = &a->c; in = &a->in; tab = (LevelTabP)a->tab;
+      AdArgsP ap = a;
+      C2_LAUNDER(ap);
+      in = &ap->in;
       nxt = cur;
-      nxt.lu = 0.0;
-      load_raw<HAS_QSAT>(in, o, nproma, jk + 1, !last, nxt);
-      if (!last && !HAS_QSAT) nxt.qsat = satur_point<P>(c, nxt.pap, nxt.t);
+      if (!last) load_level<HAS_QSAT>(in, o, nproma, nlev, jk + 1, nxt);
+      if (!HAS_QSAT) cur.qsat = satur_point<P>(c, cur.pap, cur.t);
       LevelCst k;
       level_cst(tab, jk, last, k);
       LevelIn x;
-      make_level_in(cur, nxt, paph_surf, x);
+      make_level_in(cur, paph_k, paph_surf, x);
       scratch[osc + (long long)jk * nproma] = cy.covptot;  // ZCOVPTOT5(JK-1)
       LevelTraj tr;
       LevelOut lo;
       level_forward<P>(c, k, rh, x, cy, tr, lo);
-      C2_LAUNDER(a);
-      c = &a->c; out = &a->out;
-      store_out(out, o, nproma, jk, c, lo);
+      C2_LAUNDER(ap);
+      out = &ap->out;
+      store_out(out, o, nproma, jk, lo);
+      paph_k = cur.paph_k1;
       cur = nxt;
     }
   }
@@ -418,18 +425,17 @@ C2_HD void ad_column(long long gcol, AdArgsP a) {
     const bool last = (jk == nlev - 1);
     const long long d = (long long)jk * nproma;
     const long long d1 = d + nproma;
-    C2_LAUNDER(a);
-    c = &a->c; in = &a->in; out = &a->out; tab = (LevelTabP)a->tab;
-    RawLevel cur, nxt;
-    load_raw<HAS_QSAT>(in, o, nproma, jk, true, cur);
+    AdArgsP ap = a;
+    C2_LAUNDER(ap);
+    in = &ap->in; out = &ap->out;
+    RawLevel cur;
+    load_level<HAS_QSAT>(in, o, nproma, nlev, jk, cur);
+    const real_t paph_k = in->paph[o.half + d];
     if (!HAS_QSAT) cur.qsat = satur_point<P>(c, cur.pap, cur.t);
-    nxt = cur;
-    nxt.paph = in->paph[o.half + d1];
-    nxt.lu = last ? 0.0 : in->lu[o.full + d1];
     LevelCst k;
     level_cst(tab, jk, last, k);
     LevelIn x;
-    make_level_in(cur, nxt, paph_surf, x);
+    make_level_in(cur, paph_k, paph_surf, x);
     Carry cy;
     cy.rfl = out->fplsl[o.half + d];  // ZRFL5(JK) = PFPLSL5(JK)
     cy.sfl = out->fplsn[o.half + d];
@@ -439,8 +445,8 @@ C2_HD void ad_column(long long gcol, AdArgsP a) {
     level_forward<P>(c, k, rh, x, cy, tr, lo);
 
     // output adjoints of this level; enthalpy-flux adjoints folded in (cloudsc2ad.F90:914-921)
-    C2_LAUNDER(a);
-    c = &a->c; aout = &a->aout;
+    C2_LAUNDER(ap);
+    aout = &ap->aout;
     LevelOut ya;
     ya.tent = aout->tent[oa.loc + d];
     ya.tenq = aout->tenq[oa.loc + d];
@@ -455,8 +461,8 @@ C2_HD void ad_column(long long gcol, AdArgsP a) {
     level_ad(c, k, x, tr, ya, acy, ax);
 
     // accumulate input adjoints (cloudsc2ad.F90:1723-1738; PSUPSAT assigned, :1733)
-    C2_LAUNDER(a);
-    ain = &a->ain; aout = &a->aout;
+    C2_LAUNDER(ap);
+    ain = &ap->ain; aout = &ap->aout;
     ain->pap[oa.full + d] += ax.pap;
     ain->q[oa.full + d] += ax.q;
     ain->qsat[oa.full + d] += ax.qs;

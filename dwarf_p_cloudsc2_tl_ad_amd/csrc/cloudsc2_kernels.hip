@@ -92,6 +92,7 @@ Consts make_consts(const cloudsc2_params& p, double ptsphy) {
   c.zlfdcp0_r = 1.0 / (p.rlmlt * c.zzz0);
   c.lregcl = p.lregcl ? 1 : 0;
   c.nlev = p.nlev;
+  fill_stage_blocks(c);
   return c;
 }
 
@@ -125,9 +126,9 @@ int get_tables(const cloudsc2_params& p, const LevelTab** dev, int* kb0, int* kb
   memset(&host, 0, sizeof(host));
   e.kb0 = p.nlev; e.kb1 = 0;
   for (int jk = 0; jk < p.nlev; ++jk) {
-    host.ceta[jk] = p.ceta[jk];
+    host.lev[jk].ceta = p.ceta[jk];
     // cloudsc2.F90:266  ZSCALM(JK)=ZSCAL*MAX((CETA(JK)-0.2),ZEPS1)**0.2, ZSCAL=0.9 (:172)
-    host.zscalm[jk] = 0.9 * pow(fmax(p.ceta[jk] - 0.2, 1.e-12), 0.2);
+    host.lev[jk].zscalm = 0.9 * pow(fmax(p.ceta[jk] - 0.2, 1.e-12), 0.2);
     if (jk < p.nlev - 1 && p.ceta[jk] > 0.1 && p.ceta[jk] < 0.4) {  // cloudsc2.F90:318-321
       if (jk < e.kb0) e.kb0 = jk;
       if (jk + 1 > e.kb1) e.kb1 = jk + 1;
@@ -146,6 +147,17 @@ int get_tables(const cloudsc2_params& p, const LevelTab** dev, int* kb0, int* kb
 // argument block; the device code reads it in place from the kernel-argument segment (scalar cache).
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kBlock = 128;
+// minimum waves per SIMD requested from the register allocator (0 = let the compiler decide)
+#ifndef C2_NL_WAVES
+#define C2_NL_WAVES 0
+#endif
+#ifndef C2_TL_WAVES
+#define C2_TL_WAVES 0
+#endif
+#ifndef C2_AD_WAVES
+#define C2_AD_WAVES 0
+#endif
+#define C2_BOUNDS(w) __launch_bounds__(kBlock, (w) > 0 ? (w) : 1)
 
 __device__ __forceinline__ long long global_column() { return (long long)blockIdx.x * blockDim.x + threadIdx.x; }
 
@@ -165,17 +177,17 @@ __global__ void __launch_bounds__(kBlock) satur_kernel(SaturArgs args) {
 }
 
 template <bool HAS_QSAT, bool PERT, bool P>
-__global__ void __launch_bounds__(kBlock) nl_kernel(NlArgs args) {
+__global__ void C2_BOUNDS(C2_NL_WAVES) nl_kernel(NlArgs args) {
   C2_KERNEL_BODY((nl_column<HAS_QSAT, PERT, P>(global_column(), kernarg<NlArgs>())));
 }
 
-template <bool HAS_QSAT, bool P>
-__global__ void __launch_bounds__(kBlock) tl_kernel(TlArgs args) {
-  C2_KERNEL_BODY((tl_column<HAS_QSAT, P>(global_column(), kernarg<TlArgs>())));
+template <bool HAS_QSAT, bool P, bool STORE_TRAJ>
+__global__ void C2_BOUNDS(C2_TL_WAVES) tl_kernel(TlArgs args) {
+  C2_KERNEL_BODY((tl_column<HAS_QSAT, P, STORE_TRAJ>(global_column(), kernarg<TlArgs>())));
 }
 
 template <bool HAS_QSAT, bool P>
-__global__ void __launch_bounds__(kBlock) ad_kernel(AdArgs args) {
+__global__ void C2_BOUNDS(C2_AD_WAVES) ad_kernel(AdArgs args) {
   C2_KERNEL_BODY((ad_column<HAS_QSAT, P>(global_column(), kernarg<AdArgs>())));
 }
 
@@ -433,7 +445,7 @@ int cloudsc2_nl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
   Strides s = {0, 0, 0, 0, 0};
   InPtrs ip; OutPtrs op;
   if ((rc = resolve_in(*in, false, s, ip))) return rc;
-  if ((rc = resolve_out(*out, false, s, op))) return rc;
+  if ((rc = resolve_out(*out, true, s, op))) return rc;
   const LevelTab* tab;
   if ((rc = get_tables(*prm, &tab, &g.kb0, &g.kb1))) return rc;
   NlArgs args;
@@ -469,6 +481,12 @@ int cloudsc2_tl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
   Strides s = {0, 0, 0, 0, 0}, sp = {0, 0, 0, 0, 0};
   InPtrs ip, dip; OutPtrs op, dop;
   if ((rc = resolve_in(*traj_in, false, s, ip))) return rc;
+  const cloudsc2_field* tf[10] = {&traj_out->tent, &traj_out->tenq, &traj_out->tenl, &traj_out->teni, &traj_out->clc,
+                                  &traj_out->fplsl, &traj_out->fplsn, &traj_out->fhpsl, &traj_out->fhpsn, &traj_out->covptot};
+  int nset = 0;
+  for (auto f : tf) nset += f->ptr ? 1 : 0;
+  if (nset != 0 && nset != 10) return fail(CLOUDSC2_EINVAL, "traj_out: give all ten trajectory outputs or none");
+  const bool store_traj = nset == 10;
   if ((rc = resolve_out(*traj_out, false, s, op))) return rc;
   if ((rc = resolve_in(*pert_in, true, sp, dip))) return rc;
   if ((rc = resolve_out(*pert_out, true, sp, dop))) return rc;
@@ -480,13 +498,16 @@ int cloudsc2_tl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
   dim3 grid(grid_for(g.ncols_pad, kBlock)), block(kBlock);
   hipStream_t st = (hipStream_t)stream;
   const bool precise = g_precise.load() != 0;
-  if (traj_in->qsat.ptr) {
-    if (precise) hipLaunchKernelGGL((tl_kernel<true, true>), grid, block, 0, st, args);
-    else hipLaunchKernelGGL((tl_kernel<true, false>), grid, block, 0, st, args);
+  const bool hq = traj_in->qsat.ptr != nullptr;
+#define C2_TL(HQ, PR, ST) hipLaunchKernelGGL((tl_kernel<HQ, PR, ST>), grid, block, 0, st, args)
+  if (store_traj) {
+    if (hq) { if (precise) C2_TL(true, true, true); else C2_TL(true, false, true); }
+    else    { if (precise) C2_TL(false, true, true); else C2_TL(false, false, true); }
   } else {
-    if (precise) hipLaunchKernelGGL((tl_kernel<false, true>), grid, block, 0, st, args);
-    else hipLaunchKernelGGL((tl_kernel<false, false>), grid, block, 0, st, args);
+    if (hq) { if (precise) C2_TL(true, true, false); else C2_TL(true, false, false); }
+    else    { if (precise) C2_TL(false, true, false); else C2_TL(false, false, false); }
   }
+#undef C2_TL
   HIP_TRY(hipGetLastError());
   return 0;
 }

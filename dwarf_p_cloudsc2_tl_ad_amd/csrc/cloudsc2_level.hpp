@@ -108,6 +108,26 @@ C2_HD real_t c2_exp(real_t x) {
   return ldexp(p, (int)n);
 }
 
+struct StageBlock { real_t v[8]; };
+// k0: first guess, entry reciprocals, stage A (saturation pressure)
+enum { K0_PTSPHY, K0_R4LES, K0_R4IES, K0_RTT, K0_RLPTRC, K0_R3IES, K0_R3LES, K0_R2ES };
+// k1: stage A (dqs/dT), B, D
+enum { K1_R5LES, K1_R5IES, K1_RETV, K1_RD, K1_ZCONS3, K1_RTICE, K1_RG, K1_RLMIN };
+// k2: stages D..H
+enum { K2_PTSPHY, K2_RCPD_R, K2_ZQTMST, K2_ZCONS2, K2_ZLFDCP0_R, K2_ZMELTP2, K2_ZCONS2_R, K2_RG };
+// k6: latent heats over cp when RVTMP2 == 0
+enum { K6_ZLVDCP0, K6_ZLSDCP0, K6_ZLFDCP0, K6_SPARE0, K6_SPARE1, K6_SPARE2, K6_SPARE3, K6_SPARE4 };
+// k3: stage I (autoconversion)
+enum { K3_ZLCRIT_L_R, K3_ZCKCODTL, K3_ZLCRIT_I_R, K3_ZCKCODTI, K3_RTT, K3_ZCONS2, K3_ZLCRIT_L, K3_ZLCRIT_I };
+// k4: stages K, L (saturation adjustment)
+enum { K4_RTT, K4_R3LES, K4_R4LES, K4_R3IES, K4_R4IES, K4_R2ES, K4_RETV, K4_PTSPHY };
+// k5: stages L, M, enthalpy fluxes
+enum { K5_R5ALVCP, K5_RALVDCP, K5_R5ALSCP, K5_RALSDCP, K5_ZCONS2, K5_ZQTMST, K5_RLVTT, K5_RLSTT };
+// ks: SATUR
+enum { KS_R4LES, KS_R4IES, KS_RTT, KS_R3LES, KS_R3IES, KS_R2ES, KS_RETV, KS_SPARE };
+// kf: FOEALFA
+enum { KF_RTICE, KF_RTWAT, KF_RTWAT_RTICE_R, KF_SPARE0, KF_SPARE1, KF_SPARE2, KF_SPARE3, KF_SPARE4 };
+
 // Launch-invariant scalars: the module constants plus what CLOUDSC2 derives from them at entry
 // (cloudsc2.F90:235-244, cloudsc2tl.F90:321-332).
 struct Consts {
@@ -122,11 +142,39 @@ struct Consts {
   real_t zlcrit_l_r, zlcrit_i_r;  // 1/ZLCRIT
   real_t zlfdcp0_r;               // 1/ZLFDCP when RVTMP2 == 0
   real_t zcons2_r;                // PTSPHY*RG = 1/ZCONS2
+  // the same values grouped by stage of use (see C2_PIN8); index names below
+  StageBlock k0, k1, k2, k3, k4, k5, k6, ks, kf;
   int evap;                    // LEVAPLS2 .OR. LDRAIN1D
   int lregcl;
   int rvtmp2_zero;
   int nlev;
 };
+
+// host side: derive the per-stage blocks from the flat members (call last when building a Consts)
+inline void fill_stage_blocks(Consts& c) {
+  real_t* k;
+  k = c.k0.v; k[K0_PTSPHY] = c.ptsphy; k[K0_R4LES] = c.r4les; k[K0_R4IES] = c.r4ies; k[K0_RTT] = c.rtt;
+  k[K0_RLPTRC] = c.rlptrc; k[K0_R3IES] = c.r3ies; k[K0_R3LES] = c.r3les; k[K0_R2ES] = c.r2es;
+  k = c.k1.v; k[K1_R5LES] = c.r5les; k[K1_R5IES] = c.r5ies; k[K1_RETV] = c.retv; k[K1_RD] = c.rd;
+  k[K1_ZCONS3] = c.zcons3; k[K1_RTICE] = c.rtice; k[K1_RG] = c.rg; k[K1_RLMIN] = c.rlmin;
+  k = c.k2.v; k[K2_PTSPHY] = c.ptsphy; k[K2_RCPD_R] = c.rcpd_r; k[K2_ZQTMST] = c.zqtmst; k[K2_ZCONS2] = c.zcons2;
+  k[K2_ZLFDCP0_R] = c.zlfdcp0_r; k[K2_ZMELTP2] = c.zmeltp2; k[K2_ZCONS2_R] = c.zcons2_r; k[K2_RG] = c.rg;
+  k = c.k6.v; k[K6_ZLVDCP0] = c.rlvtt * c.zzz0; k[K6_ZLSDCP0] = c.rlstt * c.zzz0; k[K6_ZLFDCP0] = c.rlmlt * c.zzz0;
+  k[K6_SPARE0] = c.zzz0;
+  k[K6_SPARE1] = k[K6_SPARE2] = k[K6_SPARE3] = k[K6_SPARE4] = 0.0;
+  k = c.k3.v; k[K3_ZLCRIT_L_R] = c.zlcrit_l_r; k[K3_ZCKCODTL] = c.zckcodtl; k[K3_ZLCRIT_I_R] = c.zlcrit_i_r;
+  k[K3_ZCKCODTI] = c.zckcodti; k[K3_RTT] = c.rtt; k[K3_ZCONS2] = c.zcons2; k[K3_ZLCRIT_L] = c.zlcrit_l;
+  k[K3_ZLCRIT_I] = c.zlcrit_i;
+  k = c.k4.v; k[K4_RTT] = c.rtt; k[K4_R3LES] = c.r3les; k[K4_R4LES] = c.r4les; k[K4_R3IES] = c.r3ies;
+  k[K4_R4IES] = c.r4ies; k[K4_R2ES] = c.r2es; k[K4_RETV] = c.retv; k[K4_PTSPHY] = c.ptsphy;
+  k = c.k5.v; k[K5_R5ALVCP] = c.r5alvcp; k[K5_RALVDCP] = c.ralvdcp; k[K5_R5ALSCP] = c.r5alscp;
+  k[K5_RALSDCP] = c.ralsdcp; k[K5_ZCONS2] = c.zcons2; k[K5_ZQTMST] = c.zqtmst; k[K5_RLVTT] = c.rlvtt;
+  k[K5_RLSTT] = c.rlstt;
+  k = c.ks.v; k[KS_R4LES] = c.r4les; k[KS_R4IES] = c.r4ies; k[KS_RTT] = c.rtt; k[KS_R3LES] = c.r3les;
+  k[KS_R3IES] = c.r3ies; k[KS_R2ES] = c.r2es; k[KS_RETV] = c.retv; k[KS_SPARE] = 0.0;
+  k = c.kf.v; k[KF_RTICE] = c.rtice; k[KF_RTWAT] = c.rtwat; k[KF_RTWAT_RTICE_R] = c.rtwat_rtice_r;
+  k[KF_SPARE0] = k[KF_SPARE1] = k[KF_SPARE2] = k[KF_SPARE3] = k[KF_SPARE4] = 0.0;
+}
 
 // Raw inputs of one level (dummy arguments of CLOUDSC2 at (JL,JK); cloudsc2.F90:124-143).
 struct LevelIn {
@@ -143,10 +191,37 @@ struct Carry {
 // Outputs of one level (cloudsc2.F90:709-715,732-733; PCOVPTOT :582).
 struct LevelOut {
   real_t tent, tenq, tenl, teni, clc, covptot, fplsl, fplsn;  // fluxes at half level JK+1
+  real_t fhpsl, fhpsn;                                        // enthalpy fluxes (cloudsc2.F90:732-733)
 };
 
 // Per-level, column-independent values prepared on the host.
 typedef const C2_CONST_AS Consts* ConstsP;
+
+// A wave has 102 SGPRs; the ~40 fp64 constants of a level plus the field pointers do not fit, and left to itself the
+// compiler sinks every constant's s_load next to its use (one exposed scalar-cache latency per constant: 42
+// `s_waitcnt lgkmcnt(0)` per level, half of the wave's lifetime).  The constants are therefore grouped by the stage that
+// uses them into 64-byte blocks; a stage copies its block with ONE s_load_dwordx16 and pins it (C2_PIN8), i.e. one
+// wait per stage, and the SGPRs are free again afterwards.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define C2_PIN8(b) asm volatile("" ::"s"((b).v[0]), "s"((b).v[1]), "s"((b).v[2]), "s"((b).v[3]), "s"((b).v[4]), "s"((b).v[5]), \
+                                 "s"((b).v[6]), "s"((b).v[7]))
+#else
+#define C2_PIN8(b) ((void)0)
+#endif
+template <class B>
+C2_HD B c2_block(const C2_CONST_AS B* p) {
+  B b = *p;
+  C2_PIN8(b);
+  return b;
+}
+// two blocks with one wait: both loads are issued before the first pin
+template <class B>
+C2_HD void c2_block2(const C2_CONST_AS B* p, const C2_CONST_AS B* q, B& a, B& b) {
+  a = *p;
+  b = *q;
+  C2_PIN8(a);
+  C2_PIN8(b);
+}
 
 struct LevelCst {
   real_t ceta, zscalm;  // CETA(JK); ZSCALM(JK) (cloudsc2.F90:266)
@@ -194,27 +269,35 @@ C2_HD real_t foealfa(ConstsP c, real_t t) {
 // SATUR, LDPHYLIN branch (src/cloudsc2_nl/satur.F90:106-123)
 template <bool P>
 C2_HD real_t satur_point(ConstsP c, real_t pap, real_t t) {
-  real_t zalfa = foealfa(c, t);
+  StageBlock kf, ks;
+  c2_block2(&c->kf, &c->ks, kf, ks);
+  real_t zalfa;
+  {  // FOEALFA (fcttre.func.h:74-75)
+    real_t xa = (fmax(kf.v[KF_RTICE], fmin(kf.v[KF_RTWAT], t)) - kf.v[KF_RTICE]) * kf.v[KF_RTWAT_RTICE_R];
+    zalfa = fmin(1.0, xa * xa);
+  }
+  const real_t r4les = ks.v[KS_R4LES], r4ies = ks.v[KS_R4IES], rtt = ks.v[KS_RTT], r3les = ks.v[KS_R3LES],
+               r3ies = ks.v[KS_R3IES], r2es = ks.v[KS_R2ES], retv = ks.v[KS_RETV];
   real_t zfoeewl, zfoeewi, zqs, zcor;
   if (P) {
-    zfoeewl = c->r2es * exp(c->r3les * (t - c->rtt) / (t - c->r4les));
-    zfoeewi = c->r2es * exp(c->r3ies * (t - c->rtt) / (t - c->r4ies));
+    zfoeewl = r2es * exp(r3les * (t - rtt) / (t - r4les));
+    zfoeewi = r2es * exp(r3ies * (t - rtt) / (t - r4ies));
     real_t zfoeew = zalfa * zfoeewl + (1.0 - zalfa) * zfoeewi;
     zqs = zfoeew / pap;
     if (zqs > 0.5) zqs = 0.5;
-    zcor = 1.0 / (1.0 - c->retv * zqs);
+    zcor = 1.0 / (1.0 - retv * zqs);
   } else {
     real_t rl, ri, rp;
-    c2_rcp3(t - c->r4les, t - c->r4ies, pap, rl, ri, rp);
-    real_t dt = t - c->rtt;
-    // the ice (liquid) branch has weight exactly 0 outside the mixed-phase range: skip its exp there
-    zfoeewl = 0.0; zfoeewi = 0.0;
-    if (zalfa > 0.0) zfoeewl = c->r2es * c2_exp(c->r3les * dt * rl);
-    if (zalfa < 1.0) zfoeewi = c->r2es * c2_exp(c->r3ies * dt * ri);
+    c2_rcp3(t - r4les, t - r4ies, pap, rl, ri, rp);
+    real_t dt = t - rtt;
+    // both branches unconditionally: a lane-divergent skip of the zero-weight exp costs more (the constant block is
+    // re-fetched inside every branch) than the ~20 instructions it saves
+    zfoeewl = r2es * c2_exp(r3les * dt * rl);
+    zfoeewi = r2es * c2_exp(r3ies * dt * ri);
     real_t zfoeew = zalfa * zfoeewl + (1.0 - zalfa) * zfoeewi;
     zqs = zfoeew * rp;
     if (zqs > 0.5) zqs = 0.5;
-    zcor = c2_rcp(1.0 - c->retv * zqs);
+    zcor = c2_rcp(1.0 - retv * zqs);
   }
   return zqs * zcor;
 }
@@ -229,6 +312,7 @@ struct LevelTraj {
   real_t zcosh2r;  // 1/cosh^2(0.17 (T-RLPTRC)) (only set when cold)
   real_t rdp;      // 1/(PAPHP1(JK+1)-PAPHP1(JK))
   real_t rden, rlu, rclc, rcons;  // 1/zden, 1/PLU(JK+1), 1/PCLC, 1/ZCONS
+  real_t rdt;      // RD*T
   int cold, esdp_clip, qlim_is_qs;
   // stage B
   real_t zcrh2, zsupsat, zqsat, zqcrit;
@@ -277,21 +361,23 @@ template <bool P>
 C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const LevelIn& x, Carry& cy,
                          LevelTraj& t, LevelOut& o) {
   const real_t zqmax = 0.5, zeps2 = 1.e-10;
+  const int rvtmp2_zero = c->rvtmp2_zero, evap = c->evap;
+
+  // ---- blocks k0 (first guess, entry reciprocals, saturation pressure) and k1 (dqs/dT, critical RH, convection) ----
+  StageBlock k0, k1;
+  c2_block2(&c->k0, &c->k1, k0, k1);
+  const real_t ptsphy = k0.v[K0_PTSPHY], rtt = k0.v[K0_RTT];
 
   // first guess (cloudsc2.F90:255-258) and thermodynamic constants (:272-276)
-  t.ztp2 = x.t + c->ptsphy * x.gt;
-  t.zqp2 = x.q + c->ptsphy * x.gq + x.supsat;
-  t.zl = x.l + c->ptsphy * x.gl;
-  t.zi = x.i + c->ptsphy * x.gi;
+  t.ztp2 = x.t + ptsphy * x.gt;
+  t.zqp2 = x.q + ptsphy * x.gq + x.supsat;
+  t.zl = x.l + ptsphy * x.gl;
+  t.zi = x.i + ptsphy * x.gi;
   t.zdp = x.paph_k1 - x.paph_k;
-  t.zzz = c->rvtmp2_zero ? c->zzz0 : recip<P>(c->rcpd + c->rcpd * c->rvtmp2 * t.zqp2);
-  t.zlfdcp = c->rlmlt * t.zzz;
-  t.zlsdcp = c->rlstt * t.zzz;
-  t.zlvdcp = c->rlvtt * t.zzz;
 
   // reciprocals known at level entry: 1/(T-R4LES), 1/(T-R4IES), 1/p, 1/dp from ONE v_rcp_f64
-  t.tm4l = t.ztp2 - c->r4les;
-  t.tm4i = t.ztp2 - c->r4ies;
+  t.tm4l = t.ztp2 - k0.v[K0_R4LES];
+  t.tm4i = t.ztp2 - k0.v[K0_R4IES];
   real_t rl = 0.0, ri = 0.0, rp, rdp;
   if (P) {
     rp = 1.0 / x.pap;
@@ -310,55 +396,59 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
   t.rdp = rdp;
 
   // A. mixed phase and dqs/dT (cloudsc2.F90:350-375, LPHYLIN branch)
+  t.cold = t.ztp2 < rtt;
   {
-    t.cold = t.ztp2 < c->rtt;
     real_t z3es, z4es, r4;
     if (P) {
-      real_t u = 0.17 * (t.ztp2 - c->rlptrc);
+      real_t u = 0.17 * (t.ztp2 - k0.v[K0_RLPTRC]);
       real_t ch = cosh(u);  // TL/AD only
       t.zcosh2r = 1.0 / (ch * ch);
       real_t zoealfaw = 0.545 * (tanh(u) + 1.0);
-      if (t.cold) { t.zfwat = zoealfaw; z3es = c->r3ies; z4es = c->r4ies; }
-      else        { t.zfwat = 1.0;      z3es = c->r3les; z4es = c->r4les; }
+      if (t.cold) { t.zfwat = zoealfaw; z3es = k0.v[K0_R3IES]; z4es = k0.v[K0_R4IES]; }
+      else        { t.zfwat = 1.0;      z3es = k0.v[K0_R3LES]; z4es = k0.v[K0_R4LES]; }
       r4 = 0.0;
     } else if (t.cold) {
       // tanh(u)+1 = 2 e^{2u}/(e^{2u}+1),  1/cosh^2(u) = 4 e^{2u}/(e^{2u}+1)^2,  u = 0.17 (T - RLPTRC)
-      real_t e2 = c2_exp(0.34 * (t.ztp2 - c->rlptrc));
+      real_t e2 = c2_exp(0.34 * (t.ztp2 - k0.v[K0_RLPTRC]));
       real_t re = c2_rcp(e2 + 1.0);
       real_t th1 = 2.0 * e2 * re;
       t.zcosh2r = 2.0 * th1 * re;
       t.zfwat = 0.545 * th1;
-      z3es = c->r3ies; z4es = c->r4ies; r4 = ri;
+      z3es = k0.v[K0_R3IES]; z4es = k0.v[K0_R4IES]; r4 = ri;
     } else {
       t.zcosh2r = 0.0;  // only read when cold
       t.zfwat = 1.0;
-      z3es = c->r3les; z4es = c->r4les; r4 = rl;
+      z3es = k0.v[K0_R3LES]; z4es = k0.v[K0_R4LES]; r4 = rl;
     }
-    t.zfoeew = c->r2es * ex<P>(quot<P>(z3es * (t.ztp2 - c->rtt), t.ztp2 - z4es, r4));
+    t.zfoeew = k0.v[K0_R2ES] * ex<P>(quot<P>(z3es * (t.ztp2 - rtt), t.ztp2 - z4es, r4));
+  }
+
+  const real_t retv = k1.v[K1_RETV], rg = k1.v[K1_RG];
+  {
     real_t zesdp1 = quot<P>(t.zfoeew, x.pap, rp);
     t.esdp_clip = zesdp1 > zqmax;
     t.zesdp = t.esdp_clip ? zqmax : zesdp1;
-    t.zfacw = quot<P>(c->r5les, t.tm4l * t.tm4l, rl * rl);
-    t.zfaci = quot<P>(c->r5ies, t.tm4i * t.tm4i, ri * ri);
+    t.zfacw = quot<P>(k1.v[K1_R5LES], t.tm4l * t.tm4l, rl * rl);
+    t.zfaci = quot<P>(k1.v[K1_R5IES], t.tm4i * t.tm4i, ri * ri);
     t.zfac = t.zfwat * t.zfacw + (1.0 - t.zfwat) * t.zfaci;
+    t.rdt = k1.v[K1_RD] * t.ztp2;
     if (P) {
-      t.zcor = 1.0 / (1.0 - c->retv * t.zesdp);
-      t.zfac1 = 1.0 / (c->rd * t.ztp2);
-      t.zfac2 = 1.0 / (x.pap - c->retv * t.zfoeew);
+      t.zcor = 1.0 / (1.0 - retv * t.zesdp);
+      t.zfac1 = 1.0 / t.rdt;
+      t.zfac2 = 1.0 / (x.pap - retv * t.zfoeew);
     } else {
       // 1/(1-RETV*esdp), 1/(RD*T), 1/(p-RETV*es) share one reciprocal (used in A and E)
-      c2_rcp3(1.0 - c->retv * t.zesdp, c->rd * t.ztp2, x.pap - c->retv * t.zfoeew, t.zcor, t.zfac1, t.zfac2);
+      c2_rcp3(1.0 - retv * t.zesdp, t.rdt, x.pap - retv * t.zfoeew, t.zcor, t.zfac1, t.zfac2);
     }
     t.zdqsdtemp = t.zfac * t.zcor * x.qs;
-    t.zcorqs = 1.0 + c->zcons3 * t.zdqsdtemp;
+    t.zcorqs = 1.0 + k1.v[K1_ZCONS3] * t.zdqsdtemp;
     t.qlim_is_qs = t.zqp2 > x.qs;
     t.zqlim = t.qlim_is_qs ? x.qs : t.zqp2;
   }
 
-  C2_LAUNDER(c);
   // B. critical relative humidity (cloudsc2.F90:384-407)
   t.zcrh2 = rhcrit_level(rh, k.ceta);
-  t.below_rtice = t.ztp2 < c->rtice;
+  t.below_rtice = t.ztp2 < k1.v[K1_RTICE];
   t.zsupsat = t.below_rtice ? (1.8 - 3.e-03 * t.ztp2) : 1.0;
   t.zqsat = x.qs * t.zsupsat;
   t.zqcrit = t.zcrh2 * t.zqsat;
@@ -382,9 +472,9 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
   }
 
   // D. convective component (cloudsc2.F90:432-443)
-  t.zgdp = quot<P>(c->rg, x.paph_k1 - x.paph_k, rdp);
-  t.zlude = x.lude * c->ptsphy * t.zgdp;
-  t.llo1 = (!k.last) && (t.zlude >= c->rlmin) && (x.lu_k1 >= zeps2);
+  t.zgdp = quot<P>(rg, x.paph_k1 - x.paph_k, rdp);
+  t.zlude = x.lude * ptsphy * t.zgdp;
+  t.llo1 = (!k.last) && (t.zlude >= k1.v[K1_RLMIN]) && (x.lu_k1 >= zeps2);
   t.zexpl = 1.0; t.rlu = 0.0;
   if (t.llo1) {
     t.rlu = recip<P>(x.lu_k1);
@@ -396,17 +486,27 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
     t.zqc2 = t.zqc1;
   }
 
-  C2_LAUNDER(c);
+  // ---- blocks k2, k6: subsidence, condensation rates, melting ----
+  StageBlock k2, k6;
+  c2_block2(&c->k2, &c->k6, k2, k6);
+  if (rvtmp2_zero) {
+    t.zzz = k6.v[K6_SPARE0];  // = zzz0
+    t.zlvdcp = k6.v[K6_ZLVDCP0]; t.zlsdcp = k6.v[K6_ZLSDCP0]; t.zlfdcp = k6.v[K6_ZLFDCP0];
+  } else {
+    t.zzz = recip<P>(c->rcpd + c->rcpd * c->rvtmp2 * t.zqp2);
+    t.zlfdcp = c->rlmlt * t.zzz; t.zlsdcp = c->rlstt * t.zzz; t.zlvdcp = c->rlvtt * t.zzz;
+  }
+
   // E. compensating subsidence (cloudsc2.F90:449-459)
   t.zrho = x.pap * t.zfac1;
   t.zrodqsdp = -t.zrho * x.qs * t.zfac2;
   t.zldcp = t.zfwat * t.zlvdcp + (1.0 - t.zfwat) * t.zlsdcp;
   t.zfac3 = recip<P>(1.0 + t.zldcp * t.zdqsdtemp);
-  t.dtdzmo = c->rg * (c->rcpd_r - t.zldcp * t.zrodqsdp) * t.zfac3;
-  t.zdqsdz = t.zdqsdtemp * t.dtdzmo - c->rg * t.zrodqsdp;
-  t.zfac4 = P ? 1.0 / t.zrho : (c->rd * t.ztp2) * rp;  // 1/rho
+  t.dtdzmo = k2.v[K2_RG] * (k2.v[K2_RCPD_R] - t.zldcp * t.zrodqsdp) * t.zfac3;
+  t.zdqsdz = t.zdqsdtemp * t.dtdzmo - k2.v[K2_RG] * t.zrodqsdp;
+  t.zfac4 = P ? 1.0 / t.zrho : t.rdt * rp;  // 1/rho
   {
-    real_t xdq = t.zdqsdz * (x.mfu + x.mfd) * c->ptsphy * t.zfac4;
+    real_t xdq = t.zdqsdz * (x.mfu + x.mfd) * k2.v[K2_PTSPHY] * t.zfac4;
     t.llo3 = xdq < t.zqc2;
     t.zdqc = t.llo3 ? xdq : t.zqc2;
   }
@@ -415,8 +515,8 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
   // F. condensate partition and condensation rates (cloudsc2.F90:465-468)
   t.zqlwc1 = t.zqc3 * t.zfwat;
   t.zqiwc1 = t.zqc3 * (1.0 - t.zfwat);
-  t.zcondl1 = (t.zqlwc1 - t.zl) * c->zqtmst;
-  t.zcondi1 = (t.zqiwc1 - t.zi) * c->zqtmst;
+  t.zcondl1 = (t.zqlwc1 - t.zl) * k2.v[K2_ZQTMST];
+  t.zcondi1 = (t.zqiwc1 - t.zi) * k2.v[K2_ZQTMST];
 
   // G. maximum overlap of precipitation (cloudsc2.F90:476-480)
   t.covptot_in = cy.covptot;
@@ -432,16 +532,17 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
   real_t rfln, sfln;
   t.zcons = 1.0; t.rcons = 1.0; t.zz2s = 0.0; t.zsnmlt = 0.0; t.warm2 = 0; t.melt_all = 0;
   if (t.melt) {
-    if (P) t.zcons = c->zcons2 * t.zdp / t.zlfdcp;
-    else t.zcons = c->zcons2 * t.zdp * (c->rvtmp2_zero ? c->zlfdcp0_r : c2_rcp(t.zlfdcp));
-    t.warm2 = (t.ztp2 - c->zmeltp2) > 0.0;
-    t.zz2s = t.warm2 ? t.zcons * (t.ztp2 - c->zmeltp2) : 0.0;
+    const real_t zmeltp2 = k2.v[K2_ZMELTP2];
+    if (P) t.zcons = k2.v[K2_ZCONS2] * t.zdp / t.zlfdcp;
+    else t.zcons = k2.v[K2_ZCONS2] * t.zdp * (rvtmp2_zero ? k2.v[K2_ZLFDCP0_R] : c2_rcp(t.zlfdcp));
+    t.warm2 = (t.ztp2 - zmeltp2) > 0.0;
+    t.zz2s = t.warm2 ? t.zcons * (t.ztp2 - zmeltp2) : 0.0;
     t.melt_all = cy.sfl <= t.zz2s;
     t.zsnmlt = t.melt_all ? cy.sfl : t.zz2s;
     rfln = cy.rfl + t.zsnmlt;
     sfln = cy.sfl - t.zsnmlt;
     // dT = -snmlt/zcons = -snmlt * ZLFDCP / (ZCONS2*dp)
-    t.rcons = P ? 1.0 / t.zcons : t.zlfdcp * (c->zcons2_r * rdp);
+    t.rcons = P ? 1.0 / t.zcons : t.zlfdcp * (k2.v[K2_ZCONS2_R] * rdp);
     t.ztp1 = t.ztp2 - quot<P>(t.zsnmlt, t.zcons, t.rcons);
   } else {
     rfln = cy.rfl;
@@ -449,25 +550,29 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
     t.ztp1 = t.ztp2;
   }
 
-  C2_LAUNDER(c);
   // I. autoconversion to rain and snow (cloudsc2.F90:504-552)
   t.cloudy = t.clc > zeps2;
+  real_t zcons2dp = k2.v[K2_ZCONS2] * t.zdp;
+  real_t rtt3 = rtt;
   if (t.cloudy) {
+    // ---- block k3 ----
+    const StageBlock k3 = c2_block(&c->k3);
+    rtt3 = k3.v[K3_RTT];
     t.rclc = recip<P>(t.clc);
     t.zcldl = quot<P>(t.zqlwc1, t.clc, t.rclc);
-    real_t ql = quot<P>(t.zcldl, c->zlcrit_l, c->zlcrit_l_r);
+    real_t ql = quot<P>(t.zcldl, k3.v[K3_ZLCRIT_L], k3.v[K3_ZLCRIT_L_R]);
     t.zexp3 = ex<P>(-(ql * ql));
-    t.zdl = c->zckcodtl * (1.0 - t.zexp3);
+    t.zdl = k3.v[K3_ZCKCODTL] * (1.0 - t.zexp3);
     t.zexpdl = ex<P>(-t.zdl);
     real_t zlnew = t.clc * t.zcldl * t.zexpdl;
     t.zprr = t.zqlwc1 - zlnew;
     t.zqlwc = t.zqlwc1 - t.zprr;
 
     t.zcldi = quot<P>(t.zqiwc1, t.clc, t.rclc);
-    real_t qi = quot<P>(t.zcldi, c->zlcrit_i, c->zlcrit_i_r);
-    t.zexp1 = ex<P>(0.025 * (t.ztp1 - c->rtt));
+    real_t qi = quot<P>(t.zcldi, k3.v[K3_ZLCRIT_I], k3.v[K3_ZLCRIT_I_R]);
+    t.zexp1 = ex<P>(0.025 * (t.ztp1 - rtt3));
     t.zexp2 = ex<P>(-(qi * qi));
-    t.zdi = c->zckcodti * t.zexp1 * (1.0 - t.zexp2);
+    t.zdi = k3.v[K3_ZCKCODTI] * t.zexp1 * (1.0 - t.zexp2);
     t.zexpdi = ex<P>(-t.zdi);
     real_t zinew = t.clc * t.zcldi * t.zexpdi;
     t.zprs = t.zqiwc1 - zinew;
@@ -477,10 +582,15 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
     t.zcldl = 0.0; t.zexp3 = 1.0; t.zdl = 0.0; t.zexpdl = 1.0; t.zprr = 0.0; t.zqlwc = t.zqlwc1;
     t.zcldi = 0.0; t.zexp1 = 1.0; t.zexp2 = 1.0; t.zdi = 0.0; t.zexpdi = 1.0; t.zprs = 0.0; t.zqiwc = t.zqiwc1;
   }
-  t.zdr1 = c->zcons2 * t.zdp * (t.zprr + t.zprs);
-  t.frz1 = t.ztp1 < c->rtt;
-  if (t.frz1) { t.zrfreeze1 = c->zcons2 * t.zdp * t.zprr; t.zfwatr1 = 0.0; }
-  else        { t.zrfreeze1 = 0.0;                        t.zfwatr1 = 1.0; }
+
+  // ---- blocks k4 (first guess after the cloud processes, saturation adjustment) and k5 (adjustment, tendencies) ----
+  StageBlock k4, k5;
+  c2_block2(&c->k4, &c->k5, k4, k5);
+  const real_t rtt4 = k4.v[K4_RTT], ptsphy4 = k4.v[K4_PTSPHY], retv4 = k4.v[K4_RETV], r2es4 = k4.v[K4_R2ES];
+  t.zdr1 = zcons2dp * (t.zprr + t.zprs);
+  t.frz1 = t.ztp1 < rtt4;
+  if (t.frz1) { t.zrfreeze1 = zcons2dp * t.zprr; t.zfwatr1 = 0.0; }
+  else        { t.zrfreeze1 = 0.0;               t.zfwatr1 = 1.0; }
   rfln = rfln + t.zfwatr1 * t.zdr1;
   sfln = sfln + (1.0 - t.zfwatr1) * t.zdr1;
   t.rfln2 = rfln;
@@ -488,7 +598,7 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
 
   // J. evaporation of precipitation (cloudsc2.F90:556-591); dead unless LEVAPLS2 .OR. LDRAIN1D
   t.zprtot = rfln + sfln;
-  t.llo2 = c->evap && (t.zprtot > zeps2) && (t.covpclr > zeps2);
+  t.llo2 = evap && (t.zprtot > zeps2) && (t.covpclr > zeps2);
   real_t covptot = t.covptot1;
   real_t pcovptot = 0.0;
   t.zevapr = 0.0; t.zevaps = 0.0;
@@ -501,8 +611,8 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
     t.zqe = x.qs - (x.qs - t.zqlim) * t.covpclr / (t.omc * t.omc);
     t.zsqp = sqrt(x.pap / x.paph_surf);
     t.zbeta = c->rg * c->rpecons * pow(t.zsqp / 5.09e-3 * t.zpreclr1 / t.covpclr, 0.5777);
-    t.zb = c->ptsphy * t.zbeta * (x.qs - t.zqe) / (1.0 + t.zbeta * c->ptsphy * t.zcorqs);
-    t.zdtgdp = c->ptsphy * c->rg / (x.paph_k1 - x.paph_k);
+    t.zb = ptsphy4 * t.zbeta * (x.qs - t.zqe) / (1.0 + t.zbeta * ptsphy4 * t.zcorqs);
+    t.zdtgdp = ptsphy4 * c->rg / (x.paph_k1 - x.paph_k);
     t.zdpr1 = t.covpclr * t.zb / t.zdtgdp;
     t.dpr_clip = t.zdpr1 > t.zpreclr1;
     t.zdpr = t.dpr_clip ? t.zpreclr1 : t.zdpr1;
@@ -516,7 +626,6 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
     sfln = sfln - t.zevaps;
   }
 
-  C2_LAUNDER(c);
   // K. first-guess T and q after the cloud processes (cloudsc2.F90:602-617)
   const real_t w5 = t.zfwat * t.zlvdcp + (1.0 - t.zfwat) * t.zlsdcp;
   const real_t ev = x.lude + t.zevapr + t.zevaps;
@@ -525,16 +634,16 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
     real_t zdqdt = -(t.zcondl1 + t.zcondi1) + ev * t.zgdp;
     real_t zdtdt = t.zlvdcp * t.zcondl1 + t.zlsdcp * t.zcondi1 -
                    (t.zlvdcp * t.zevapr + t.zlsdcp * t.zevaps + x.lude * w5 - lsv * t.zrfreeze1) * t.zgdp;
-    t.ztpb = t.ztp1 + c->ptsphy * zdtdt;
-    t.zqpb = t.zqp2 + c->ptsphy * zdqdt;
+    t.ztpb = t.ztp1 + ptsphy4 * zdtdt;
+    t.zqpb = t.zqp2 + ptsphy4 * zdqdt;
   }
 
   // L. saturation adjustment, two iterations (cloudsc2.F90:630-669 == cuadjtqs.F90:212-244).
   // With a = 1 - RETV*qs:  cond = (q - qs/a) / (1 + qs*z2s/a^2) = (q*a - qs)*a / (a^2 + qs*z2s): one reciprocal
   // for the exp argument and z2s, one for the quotient.  a_cor/a_qsat/a_den (TL/AD only) are derived from them.
   {
-    if (t.ztpb > c->rtt) { t.z3es = c->r3les; t.z4es = c->r4les; t.z5alcp = c->r5alvcp; t.zaldcp = c->ralvdcp; }
-    else                { t.z3es = c->r3ies; t.z4es = c->r4ies; t.z5alcp = c->r5alscp; t.zaldcp = c->ralsdcp; }
+    if (t.ztpb > rtt4) { t.z3es = k4.v[K4_R3LES]; t.z4es = k4.v[K4_R4LES]; t.z5alcp = k5.v[K5_R5ALVCP]; t.zaldcp = k5.v[K5_RALVDCP]; }
+    else               { t.z3es = k4.v[K4_R3IES]; t.z4es = k4.v[K4_R4IES]; t.z5alcp = k5.v[K5_R5ALSCP]; t.zaldcp = k5.v[K5_RALSDCP]; }
     real_t tt = t.ztpb, qq = t.zqpb;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -544,12 +653,12 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
       real_t zcond1;
       if (P) {
         t.a_rtm4[it] = 1.0 / t.a_tm4[it];
-        t.a_foeew[it] = c->r2es * exp(t.z3es * (tt - c->rtt) / t.a_tm4[it]);
+        t.a_foeew[it] = r2es4 * exp(t.z3es * (tt - rtt4) / t.a_tm4[it]);
         real_t qs1 = t.zqp * t.a_foeew[it];
         t.a_clip[it] = qs1 > zqmax;
         if (t.a_clip[it]) qs1 = zqmax;
         t.a_qsatu[it] = qs1;
-        t.a_cor[it] = 1.0 / (1.0 - c->retv * qs1);
+        t.a_cor[it] = 1.0 / (1.0 - retv4 * qs1);
         t.a_qsat[it] = qs1 * t.a_cor[it];
         t.a_z2s[it] = t.z5alcp / (t.a_tm4[it] * t.a_tm4[it]);
         t.a_den[it] = 1.0 + t.a_qsat[it] * t.a_cor[it] * t.a_z2s[it];
@@ -558,12 +667,12 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
       } else {
         real_t r4 = c2_rcp(t.a_tm4[it]);
         t.a_rtm4[it] = r4;
-        t.a_foeew[it] = c->r2es * c2_exp(t.z3es * (tt - c->rtt) * r4);
+        t.a_foeew[it] = r2es4 * c2_exp(t.z3es * (tt - rtt4) * r4);
         real_t qs1 = t.zqp * t.a_foeew[it];
         t.a_clip[it] = qs1 > zqmax;
         if (t.a_clip[it]) qs1 = zqmax;
         t.a_qsatu[it] = qs1;
-        real_t a = 1.0 - c->retv * qs1;
+        real_t a = 1.0 - retv4 * qs1;
         t.a_z2s[it] = t.z5alcp * (r4 * r4);
         real_t d = a * a + qs1 * t.a_z2s[it];
         real_t rd = c2_rcp(d);
@@ -581,19 +690,19 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
     t.zqp1 = qq;
   }
 
-  C2_LAUNDER(c);
   // M. extra condensation goes to precipitation; final tendencies (cloudsc2.F90:673-716)
   {
+    const real_t zqtmst = k5.v[K5_ZQTMST];
     real_t d = t.zqpb - t.zqp1;
     t.dq_pos = d >= 0.0;
     t.zdq = t.dq_pos ? d : 0.0;
-    t.zdr2 = c->zcons2 * t.zdp * t.zdq;
-    t.frz2 = t.ztp3 < c->rtt;
+    t.zdr2 = k5.v[K5_ZCONS2] * t.zdp * t.zdq;
+    t.frz2 = t.ztp3 < rtt4;
     real_t zrfreeze2;
     if (t.frz2) { zrfreeze2 = t.zfwat * t.zdr2; t.zfwatr2 = 0.0; }
     else        { zrfreeze2 = 0.0;              t.zfwatr2 = 1.0; }
-    t.zcondl2 = t.zcondl1 + t.zfwatr2 * t.zdq * c->zqtmst;
-    t.zcondi2 = t.zcondi1 + (1.0 - t.zfwatr2) * t.zdq * c->zqtmst;
+    t.zcondl2 = t.zcondl1 + t.zfwatr2 * t.zdq * zqtmst;
+    t.zcondi2 = t.zcondi1 + (1.0 - t.zfwatr2) * t.zdq * zqtmst;
     rfln = rfln + t.zfwatr2 * t.zdr2;
     sfln = sfln + (1.0 - t.zfwatr2) * t.zdr2;
     t.zrfreeze3 = t.zrfreeze1 + zrfreeze2;
@@ -601,12 +710,14 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
     o.tenq = -(t.zcondl2 + t.zcondi2) + ev * t.zgdp;
     o.tent = t.zlvdcp * t.zcondl2 + t.zlsdcp * t.zcondi2 -
              (t.zlvdcp * t.zevapr + t.zlsdcp * t.zevaps + x.lude * w5 - lsv * t.zrfreeze3) * t.zgdp;
-    o.tenl = (t.zqlwc - t.zl) * c->zqtmst;
-    o.teni = (t.zqiwc - t.zi) * c->zqtmst;
+    o.tenl = (t.zqlwc - t.zl) * zqtmst;
+    o.teni = (t.zqiwc - t.zi) * zqtmst;
     o.clc = t.clc;
     o.covptot = pcovptot;
     o.fplsl = rfln;
     o.fplsn = sfln;
+    o.fhpsl = -rfln * k5.v[K5_RLVTT];
+    o.fhpsn = -sfln * k5.v[K5_RLSTT];
   }
 
   // N. carry (cloudsc2.F90:720-723)
@@ -844,6 +955,8 @@ C2_HD void level_tl(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
     dout.covptot = pcovptot;
     dout.fplsl = zrfln;
     dout.fplsn = zsfln;
+    dout.fhpsl = -zrfln * c->rlvtt;  // cloudsc2tl.F90:1108-1111
+    dout.fhpsn = -zsfln * c->rlstt;
   }
 
   dcy.rfl = zrfln;

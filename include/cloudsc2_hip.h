@@ -106,8 +106,8 @@ int cloudsc2_nl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
 int cloudsc2_satur_launch(const cloudsc2_params* prm, int nproma, int nlev, int ngptot,
                           cloudsc2_field pap, cloudsc2_field t, cloudsc2_field qsat, void* stream);
 
-/* CLOUDSC2TL (src/cloudsc2_tl/cloudsc2tl.F90:10-24): trajectory in -> trajectory out (traj_out fields
- * may have ptr NULL to skip the store), perturbation in -> perturbation out.  traj_in->qsat NULL => fused
+/* CLOUDSC2TL (src/cloudsc2_tl/cloudsc2tl.F90:10-24): trajectory in -> trajectory out (give all ten traj_out
+ * fields, or all NULL to skip the trajectory stores), perturbation in -> perturbation out.  traj_in->qsat NULL => fused
  * SATUR for PQS5.  pert_in must give all 16 fields. */
 int cloudsc2_tl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
                        const cloudsc2_inputs* traj_in, const cloudsc2_outputs* traj_out,

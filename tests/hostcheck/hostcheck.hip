@@ -41,6 +41,7 @@ static Consts hc_consts(const cloudsc2_params& p, double ptsphy) {
   c.zlfdcp0_r = 1.0 / (p.rlmlt * c.zzz0);
   c.lregcl = p.lregcl ? 1 : 0;
   c.nlev = p.nlev;
+  fill_stage_blocks(c);
   return c;
 }
 
@@ -48,8 +49,8 @@ static void hc_tables(const cloudsc2_params& p, LevelTab& tab, Geom& g) {
   memset(&tab, 0, sizeof(tab));
   g.kb0 = p.nlev; g.kb1 = 0;
   for (int jk = 0; jk < p.nlev; ++jk) {
-    tab.ceta[jk] = p.ceta[jk];
-    tab.zscalm[jk] = 0.9 * pow(fmax(p.ceta[jk] - 0.2, 1.e-12), 0.2);
+    tab.lev[jk].ceta = p.ceta[jk];
+    tab.lev[jk].zscalm = 0.9 * pow(fmax(p.ceta[jk] - 0.2, 1.e-12), 0.2);
     if (jk < p.nlev - 1 && p.ceta[jk] > 0.1 && p.ceta[jk] < 0.4) {
       if (jk < g.kb0) g.kb0 = jk;
       if (jk + 1 > g.kb1) g.kb1 = jk + 1;
@@ -132,8 +133,8 @@ int hostcheck_tl(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev
   a.s = Strides{0, 0, 0, 0, 0}; a.sp = Strides{0, 0, 0, 0, 0};
   hc_in(*in, a.s, a.in); hc_out(*out, a.s, a.out); hc_in(*din, a.sp, a.din); hc_out(*dout, a.sp, a.dout);
   for (long long gc = 0; gc < a.g.ncols_pad; ++gc) {
-    if (g_hc_precise) { if (in->qsat.ptr) tl_column<true, true>(gc, &a); else tl_column<false, true>(gc, &a); }
-    else { if (in->qsat.ptr) tl_column<true, false>(gc, &a); else tl_column<false, false>(gc, &a); }
+    if (g_hc_precise) { if (in->qsat.ptr) tl_column<true, true, true>(gc, &a); else tl_column<false, true, true>(gc, &a); }
+    else { if (in->qsat.ptr) tl_column<true, false, true>(gc, &a); else tl_column<false, false, true>(gc, &a); }
   }
   return 0;
 }
