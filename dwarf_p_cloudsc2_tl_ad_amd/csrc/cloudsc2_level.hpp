@@ -313,6 +313,7 @@ struct LevelTraj {
   real_t rdp;      // 1/(PAPHP1(JK+1)-PAPHP1(JK))
   real_t rden, rlu, rclc, rcons;  // 1/zden, 1/PLU(JK+1), 1/PCLC, 1/ZCONS
   real_t rdt;      // RD*T
+  real_t rl, ri, rtp2, rzsqrt, rlfdcp;  // 1/(T-R4LES), 1/(T-R4IES), 1/T, 1/zsqrt, 1/ZLFDCP
   int cold, esdp_clip, qlim_is_qs;
   // stage B
   real_t zcrh2, zsupsat, zqsat, zqcrit;
@@ -382,6 +383,8 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
   if (P) {
     rp = 1.0 / x.pap;
     rdp = 1.0 / t.zdp;
+    rl = 1.0 / t.tm4l;  // TL/AD only
+    ri = 1.0 / t.tm4i;
   } else {
     real_t li = t.tm4l * t.tm4i;
     real_t pd = x.pap * t.zdp;
@@ -394,6 +397,8 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
   }
   t.zqp = rp;
   t.rdp = rdp;
+  t.rl = rl;
+  t.ri = ri;
 
   // A. mixed phase and dqs/dT (cloudsc2.F90:350-375, LPHYLIN branch)
   t.cold = t.ztp2 < rtt;
@@ -440,6 +445,7 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
       // 1/(1-RETV*esdp), 1/(RD*T), 1/(p-RETV*es) share one reciprocal (used in A and E)
       c2_rcp3(1.0 - retv * t.zesdp, t.rdt, x.pap - retv * t.zfoeew, t.zcor, t.zfac1, t.zfac2);
     }
+    t.rtp2 = t.zfac1 * k1.v[K1_RD];  // 1/T (TL/AD only)
     t.zdqsdtemp = t.zfac * t.zcor * x.qs;
     t.zcorqs = 1.0 + k1.v[K1_ZCONS3] * t.zdqsdtemp;
     t.qlim_is_qs = t.zqp2 > x.qs;
@@ -455,7 +461,7 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
 
   // C. uniform-PDF cloud cover (cloudsc2.F90:413-426)
   t.zqt = t.zqp2 + t.zl + t.zi;
-  t.zqpd = 0.0; t.zqcd = 0.0; t.zden = 1.0; t.zsqrt = 1.0; t.rden = 1.0;
+  t.zqpd = 0.0; t.zqcd = 0.0; t.zden = 1.0; t.zsqrt = 1.0; t.rden = 1.0; t.rzsqrt = 1.0;
   if (t.zqt <= t.zqcrit) {
     t.regime = 0; t.zclc = 0.0; t.zqc1 = 0.0;
   } else if (t.zqt >= t.zqsat) {
@@ -467,6 +473,7 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
     t.zden = t.zqcd - k.zscalm * (t.zqt - t.zqcrit);
     t.rden = recip<P>(t.zden);
     t.zsqrt = sqrt(quot<P>(t.zqpd, t.zden, t.rden));
+    t.rzsqrt = recip<P>(t.zsqrt);  // TL/AD only
     t.zclc = 1.0 - t.zsqrt;
     t.zqc1 = (k.zscalm * t.zqpd + (1.0 - k.zscalm) * t.zqcd) * (t.zclc * t.zclc);
   }
@@ -492,9 +499,11 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
   if (rvtmp2_zero) {
     t.zzz = k6.v[K6_SPARE0];  // = zzz0
     t.zlvdcp = k6.v[K6_ZLVDCP0]; t.zlsdcp = k6.v[K6_ZLSDCP0]; t.zlfdcp = k6.v[K6_ZLFDCP0];
+    t.rlfdcp = k2.v[K2_ZLFDCP0_R];
   } else {
     t.zzz = recip<P>(c->rcpd + c->rcpd * c->rvtmp2 * t.zqp2);
     t.zlfdcp = c->rlmlt * t.zzz; t.zlsdcp = c->rlstt * t.zzz; t.zlvdcp = c->rlvtt * t.zzz;
+    t.rlfdcp = recip<P>(t.zlfdcp);
   }
 
   // E. compensating subsidence (cloudsc2.F90:449-459)
@@ -534,7 +543,7 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
   if (t.melt) {
     const real_t zmeltp2 = k2.v[K2_ZMELTP2];
     if (P) t.zcons = k2.v[K2_ZCONS2] * t.zdp / t.zlfdcp;
-    else t.zcons = k2.v[K2_ZCONS2] * t.zdp * (rvtmp2_zero ? k2.v[K2_ZLFDCP0_R] : c2_rcp(t.zlfdcp));
+    else t.zcons = k2.v[K2_ZCONS2] * t.zdp * t.rlfdcp;
     t.warm2 = (t.ztp2 - zmeltp2) > 0.0;
     t.zz2s = t.warm2 ? t.zcons * (t.ztp2 - zmeltp2) : 0.0;
     t.melt_all = cy.sfl <= t.zz2s;
@@ -726,6 +735,13 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
   cy.covptot = covptot;
 }
 
+// Regularisation of the cloud-fraction perturbation (cloudsc2tl.F90:575-580, cloudsc2ad.F90:1554-1559)
+C2_HD real_t regcl_factor(real_t zqpd5, real_t zqcd5, real_t zscalm) {
+  real_t zrat = zqpd5 * c2_rcp(zqcd5);
+  real_t w = 1.0 - zscalm * (1.0 - zrat);
+  return fmin(0.3, 3.5 * sqrt(zrat * (w * w * w)) * c2_rcp(1.0 - zscalm));
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Tangent-linear of one level about LevelTraj.  cloudsc2tl.F90:343-373 (first guess) + :457-1099,
 // CUADJTQSTL KCALL=0 (cuadjtqstl.F90:333-405).  dx = perturbation inputs, dcy = perturbation carries.
@@ -742,14 +758,16 @@ C2_HD void level_tl(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
   real_t zlfdcp = c->rlmlt * zzz, zlsdcp = c->rlstt * zzz, zlvdcp = c->rlvtt * zzz;
 
   // A (cloudsc2tl.F90:463-501)
-  real_t zfwat, z3es, z4es, tm4;
-  if (t.cold) { zfwat = 0.545 * 0.17 * ztp1 * t.zcosh2r; z3es = c->r3ies; z4es = c->r4ies; tm4 = t.tm4i; }
-  else        { zfwat = 0.0;                            z3es = c->r3les; z4es = c->r4les; tm4 = t.tm4l; }
-  real_t zfoeew = z3es * (c->rtt - z4es) * ztp1 * t.zfoeew / (tm4 * tm4);
-  real_t zesdp = zfoeew / x.pap - dx.pap * t.zfoeew / (x.pap * x.pap);
+  // quotients of the reference are products with the trajectory's reciprocals (LevelTraj::rl, ri, zqp, rdp, ...)
+  real_t zfwat, z3es, z4es, r4;
+  if (t.cold) { zfwat = 0.545 * 0.17 * ztp1 * t.zcosh2r; z3es = c->r3ies; z4es = c->r4ies; r4 = t.ri; }
+  else        { zfwat = 0.0;                            z3es = c->r3les; z4es = c->r4les; r4 = t.rl; }
+  const real_t rp = t.zqp;
+  real_t zfoeew = z3es * (c->rtt - z4es) * ztp1 * t.zfoeew * (r4 * r4);
+  real_t zesdp = zfoeew * rp - dx.pap * t.zfoeew * (rp * rp);
   if (t.esdp_clip) zesdp = 0.0;
-  real_t zfacw = -2.0 * c->r5les * ztp1 / (t.tm4l * t.tm4l * t.tm4l);
-  real_t zfaci = -2.0 * c->r5ies * ztp1 / (t.tm4i * t.tm4i * t.tm4i);
+  real_t zfacw = -2.0 * c->r5les * ztp1 * (t.rl * t.rl * t.rl);
+  real_t zfaci = -2.0 * c->r5ies * ztp1 * (t.ri * t.ri * t.ri);
   real_t zfac = t.zfwat * zfacw + t.zfacw * zfwat + (1.0 - t.zfwat) * zfaci - t.zfaci * zfwat;
   real_t zcor = c->retv * zesdp * (t.zcor * t.zcor);
   real_t zdqsdtemp = t.zfac * t.zcor * dx.qs + t.zfac * x.qs * zcor + t.zcor * x.qs * zfac;
@@ -771,30 +789,25 @@ C2_HD void level_tl(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
   } else {
     real_t zqpd = zqsat - zqt;
     real_t zqcd = zqsat - zqcrit;
-    pclc = -(0.5 / t.zsqrt) * (zqpd * t.zden - t.zqpd * (zqcd - k.zscalm * (zqt - zqcrit))) / (t.zden * t.zden);
-    if (c->lregcl) {
-      real_t zrat = t.zqpd / t.zqcd;
-      real_t w = 1.0 - k.zscalm * (1.0 - zrat);
-      real_t zyyy = fmin(0.3, 3.5 * sqrt(zrat * (w * w * w)) / (1.0 - k.zscalm));
-      pclc = zyyy * pclc;
-    }
+    pclc = -(0.5 * t.rzsqrt) * (zqpd * t.zden - t.zqpd * (zqcd - k.zscalm * (zqt - zqcrit))) * (t.rden * t.rden);
+    if (c->lregcl) pclc = regcl_factor(t.zqpd, t.zqcd, k.zscalm) * pclc;
     zqc = (k.zscalm * zqpd + (1.0 - k.zscalm) * zqcd) * (t.zclc * t.zclc) +
           (k.zscalm * t.zqpd + (1.0 - k.zscalm) * t.zqcd) * 2.0 * t.zclc * pclc;
   }
 
   // D (cloudsc2tl.F90:595-622)
-  real_t dpk = x.paph_k1 - x.paph_k;
-  real_t zgdp = -c->rg * (dx.paph_k1 - dx.paph_k) / (dpk * dpk);
+  const real_t rdp2 = t.rdp * t.rdp;
+  real_t zgdp = -c->rg * (dx.paph_k1 - dx.paph_k) * rdp2;
   real_t zlude = c->ptsphy * t.zgdp * dx.lude + c->ptsphy * x.lude * zgdp;
   if (t.llo1) {
-    pclc = pclc - pclc * (1.0 - t.zexpl) + ((1.0 - t.zclc) / x.lu_k1) * t.zexpl * zlude -
-           ((1.0 - t.zclc) * t.zlude / (x.lu_k1 * x.lu_k1)) * t.zexpl * dx.lu_k1;
+    pclc = pclc - pclc * (1.0 - t.zexpl) + ((1.0 - t.zclc) * t.rlu) * t.zexpl * zlude -
+           ((1.0 - t.zclc) * t.zlude * (t.rlu * t.rlu)) * t.zexpl * dx.lu_k1;
     zqc = zqc + zlude;
   }
 
   // E (cloudsc2tl.F90:628-664)
   {
-    real_t zrho = (dx.pap - ztp1 * x.pap / t.ztp2) * t.zfac1;
+    real_t zrho = (dx.pap - ztp1 * x.pap * t.rtp2) * t.zfac1;
     real_t zrodqsdp = (-zrho * x.qs - t.zrho * dx.qs + t.zrho * x.qs * (dx.pap - c->retv * zfoeew) * t.zfac2) * t.zfac2;
     real_t zldcp = zfwat * t.zlvdcp + t.zfwat * zlvdcp + (1.0 - t.zfwat) * zlsdcp - zfwat * t.zlsdcp;
     real_t dtdzmo = -(c->rg * (zldcp * t.zrodqsdp + t.zldcp * zrodqsdp) +
@@ -824,12 +837,12 @@ C2_HD void level_tl(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
   // H (cloudsc2tl.F90:704-733)
   real_t zrfln, zsfln;
   if (t.melt) {
-    real_t zcons = c->zcons2 * (zdp * t.zlfdcp - t.zdp * zlfdcp) / (t.zlfdcp * t.zlfdcp);
+    real_t zcons = c->zcons2 * (zdp * t.zlfdcp - t.zdp * zlfdcp) * (t.rlfdcp * t.rlfdcp);
     real_t zz2s = t.warm2 ? (t.zcons * ztp1 + zcons * (t.ztp2 - c->zmeltp2)) : 0.0;
     real_t zsnmlt = t.melt_all ? dcy.sfl : zz2s;
     zrfln = dcy.rfl + zsnmlt;
     zsfln = dcy.sfl - zsnmlt;
-    ztp1 = ztp1 - (zsnmlt * t.zcons - zcons * t.zsnmlt) / (t.zcons * t.zcons);
+    ztp1 = ztp1 - (zsnmlt * t.zcons - zcons * t.zsnmlt) * (t.rcons * t.rcons);
   } else {
     zrfln = dcy.rfl;
     zsfln = dcy.sfl;
@@ -838,17 +851,18 @@ C2_HD void level_tl(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
   // I (cloudsc2tl.F90:739-840)
   real_t zprr = 0.0, zprs = 0.0;
   if (t.cloudy) {
-    real_t zcldl = zqlwc / t.clc - t.zqlwc1 * pclc / (t.clc * t.clc);
+    const real_t rclc2 = t.rclc * t.rclc;
+    real_t zcldl = zqlwc * t.rclc - t.zqlwc1 * pclc * rclc2;
     real_t ck = c->lregcl ? c->zckcodtla : c->zckcodtl;
-    real_t zd = (2.0 * ck / (c->zlcrit_l * c->zlcrit_l)) * t.zexp3 * t.zcldl * zcldl;
+    real_t zd = (2.0 * ck * (c->zlcrit_l_r * c->zlcrit_l_r)) * t.zexp3 * t.zcldl * zcldl;
     real_t zlnew = t.zcldl * t.zexpdl * pclc + t.clc * t.zexpdl * zcldl - t.clc * t.zcldl * t.zexpdl * zd;
     zprr = zqlwc - zlnew;
     zqlwc = zqlwc - zprr;
 
-    real_t zcldi = zqiwc / t.clc - t.zqiwc1 * pclc / (t.clc * t.clc);
+    real_t zcldi = zqiwc * t.rclc - t.zqiwc1 * pclc * rclc2;
     real_t cki = c->lregcl ? c->zckcodtia : c->zckcodti;
     real_t zdi = cki * t.zexp1 *
-                 (t.zexp2 * (2.0 * t.zcldi * zcldi / (c->zlcrit_i * c->zlcrit_i) - 0.025 * ztp1) + 0.025 * ztp1);
+                 (t.zexp2 * (2.0 * t.zcldi * zcldi * (c->zlcrit_i_r * c->zlcrit_i_r) - 0.025 * ztp1) + 0.025 * ztp1);
     real_t zinew = t.zcldi * t.zexpdi * pclc + t.clc * t.zexpdi * zcldi - t.clc * t.zcldi * t.zexpdi * zdi;
     zprs = zqiwc - zinew;
     zqiwc = zqiwc - zprs;
@@ -876,7 +890,7 @@ C2_HD void level_tl(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
     real_t den = 1.0 + t.zbeta * c->ptsphy * t.zcorqs;
     real_t zb = c->ptsphy * ((x.qs - t.zqe) * zbeta + t.zbeta * dx.qs - t.zbeta * zqe) / den -
                 (c->ptsphy * c->ptsphy) * t.zbeta * (x.qs - t.zqe) * (t.zbeta * zcorqs + t.zcorqs * zbeta) / (den * den);
-    real_t zdtgdp = -c->ptsphy * c->rg * (dx.paph_k1 - dx.paph_k) / (dpk * dpk);
+    real_t zdtgdp = -c->ptsphy * c->rg * (dx.paph_k1 - dx.paph_k) * rdp2;
     real_t zdpr = (t.covpclr * zb + t.zb * zcovpclr) / t.zdtgdp - t.covpclr * t.zb * zdtgdp / (t.zdtgdp * t.zdtgdp);
     if (t.dpr_clip) zdpr = zpreclr;
     zpreclr = zpreclr - zdpr;
@@ -909,18 +923,18 @@ C2_HD void level_tl(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
     real_t zqp = -dx.pap * (t.zqp * t.zqp);
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-      real_t tm4a = t.a_tm4[it];
-      real_t dfoeew = t.z3es * (c->rtt - t.z4es) * ztp1 * t.a_foeew[it] / (tm4a * tm4a);
+      const real_t r4a = t.a_rtm4[it], r4a2 = r4a * r4a;
+      real_t dfoeew = t.z3es * (c->rtt - t.z4es) * ztp1 * t.a_foeew[it] * r4a2;
       real_t dqsat = t.zqp * dfoeew + zqp * t.a_foeew[it];
       if (t.a_clip[it]) dqsat = 0.0;
       real_t dcor = (c->retv * dqsat) * (t.a_cor[it] * t.a_cor[it]);
       dqsat = t.a_qsatu[it] * dcor + dqsat * t.a_cor[it];
-      real_t dz2s = -2.0 * ztp1 * t.z5alcp / (tm4a * tm4a * tm4a);
-      real_t den = t.a_den[it];
-      real_t dcond = (zqp1 - dqsat) / den -
+      real_t dz2s = -2.0 * ztp1 * t.z5alcp * (r4a2 * r4a);
+      const real_t rden = t.a_rden[it];
+      real_t dcond = (zqp1 - dqsat) * rden -
                      (t.a_q[it] - t.a_qsat[it]) *
                          (dqsat * t.a_cor[it] * t.a_z2s[it] + t.a_qsat[it] * dcor * t.a_z2s[it] +
-                          t.a_qsat[it] * t.a_cor[it] * dz2s) / (den * den);
+                          t.a_qsat[it] * t.a_cor[it] * dz2s) * (rden * rden);
       ztp1 = ztp1 + t.zaldcp * dcond;
       zqp1 = zqp1 - dcond;
     }
@@ -1043,23 +1057,23 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
     real_t a_zqp = 0.0;
 #pragma unroll
     for (int it = 1; it >= 0; --it) {
-      real_t den = t.a_den[it];
-      real_t tm4a = t.a_tm4[it];
+      const real_t rden = t.a_rden[it];
+      const real_t r4a = t.a_rtm4[it], r4a2 = r4a * r4a;
       real_t zcond1 = -a_qp1 + t.zaldcp * a_tp1;
-      a_qp1 += zcond1 / den;
-      real_t zqsat = -zcond1 / den;
-      real_t dqmq = (t.a_q[it] - t.a_qsat[it]) / (den * den);
+      a_qp1 += zcond1 * rden;
+      real_t zqsat = -zcond1 * rden;
+      real_t dqmq = (t.a_q[it] - t.a_qsat[it]) * (rden * rden);
       zqsat -= zcond1 * dqmq * t.a_cor[it] * t.a_z2s[it];
       real_t zcor = -zcond1 * dqmq * t.a_qsat[it] * t.a_z2s[it];
       real_t z2s = -zcond1 * dqmq * t.a_qsat[it] * t.a_cor[it];
-      real_t ztarg = -2.0 * z2s * t.z5alcp / (tm4a * tm4a * tm4a);
+      real_t ztarg = -2.0 * z2s * t.z5alcp * (r4a2 * r4a);
       zcor += zqsat * t.a_qsatu[it];
       zqsat = zqsat * t.a_cor[it];
       zqsat += zcor * c->retv * (t.a_cor[it] * t.a_cor[it]);
       if (t.a_clip[it]) zqsat = 0.0;
       real_t zfoeew = zqsat * t.zqp;
       a_zqp += zqsat * t.a_foeew[it];
-      ztarg += zfoeew * t.z3es * (c->rtt - t.z4es) * t.a_foeew[it] / (tm4a * tm4a);
+      ztarg += zfoeew * t.z3es * (c->rtt - t.z4es) * t.a_foeew[it] * r4a2;
       a_tp1 += ztarg;
     }
     a_pap -= a_zqp * (t.zqp * t.zqp);
@@ -1115,8 +1129,7 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
     a_covpclr += t.zb * zdpr / t.zdtgdp;
     a_dtgdp -= t.covpclr * t.zb * zdpr / (t.zdtgdp * t.zdtgdp);
     {
-      real_t dpk = x.paph_k1 - x.paph_k;
-      real_t g = c->ptsphy * c->rg * a_dtgdp / (dpk * dpk);
+      real_t g = c->ptsphy * c->rg * a_dtgdp * (t.rdp * t.rdp);
       a_paph_k1 -= g;
       a_paph_k += g;
     }
@@ -1171,9 +1184,9 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
       real_t zdi = -zinew * t.clc * t.zcldi * t.zexpdi;
       real_t cki = c->lregcl ? c->zckcodtia : c->zckcodti;
       a_tp1 += cki * t.zexp1 * (1.0 - t.zexp2) * 0.025 * zdi;
-      zcldi += (cki * t.zexp1 * t.zexp2 * 2.0 * t.zcldi / (c->zlcrit_i * c->zlcrit_i)) * zdi;
-      a_qiwc += zcldi / t.clc;
-      a_clc -= t.zqiwc1 * zcldi / (t.clc * t.clc);
+      zcldi += (cki * t.zexp1 * t.zexp2 * 2.0 * t.zcldi * (c->zlcrit_i_r * c->zlcrit_i_r)) * zdi;
+      a_qiwc += zcldi * t.rclc;
+      a_clc -= t.zqiwc1 * zcldi * (t.rclc * t.rclc);
       // liquid
       zprr -= a_qlwc;
       a_qlwc += zprr;
@@ -1182,17 +1195,17 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
       real_t zcldl = zlnew * t.clc * t.zexpdl;
       real_t zdl = -zlnew * t.clc * t.zcldl * t.zexpdl;
       real_t ck = c->lregcl ? c->zckcodtla : c->zckcodtl;
-      zcldl += (2.0 * ck / (c->zlcrit_l * c->zlcrit_l)) * t.zexp3 * t.zcldl * zdl;
-      a_qlwc += zcldl / t.clc;
-      a_clc -= t.zqlwc1 * zcldl / (t.clc * t.clc);
+      zcldl += (2.0 * ck * (c->zlcrit_l_r * c->zlcrit_l_r)) * t.zexp3 * t.zcldl * zdl;
+      a_qlwc += zcldl * t.rclc;
+      a_clc -= t.zqlwc1 * zcldl * (t.rclc * t.rclc);
     }
   }
 
   // H^T: melting of incoming snow (cloudsc2ad.F90:1362-1400)
   real_t a_sfl = 0.0, a_rfl = 0.0;
   if (t.melt) {
-    real_t zsnmlt = -a_tp1 / t.zcons;
-    real_t zcons = (a_tp1 * t.zsnmlt) / (t.zcons * t.zcons);
+    real_t zsnmlt = -a_tp1 * t.rcons;
+    real_t zcons = (a_tp1 * t.zsnmlt) * (t.rcons * t.rcons);
     a_sfl += a_sfln;
     zsnmlt -= a_sfln;
     a_rfl += a_rfln;
@@ -1203,8 +1216,8 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
       a_tp1 += t.zcons * zz2s;
       zcons += (t.ztp2 - c->zmeltp2) * zz2s;
     }
-    a_dp += c->zcons2 * zcons / t.zlfdcp;
-    a_lfdcp -= c->zcons2 * t.zdp * zcons / (t.zlfdcp * t.zlfdcp);
+    a_dp += c->zcons2 * zcons * t.rlfdcp;
+    a_lfdcp -= c->zcons2 * t.zdp * zcons * (t.rlfdcp * t.rlfdcp);
   } else {
     a_sfl += a_sfln;
     a_rfl += a_rfln;
@@ -1252,7 +1265,7 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
     a_pap += zrodqsdp * t.zrho * x.qs * (t.zfac2 * t.zfac2);
     a_foeew -= zrodqsdp * t.zrho * x.qs * c->retv * (t.zfac2 * t.zfac2);
     a_pap += zrho * t.zfac1;
-    a_tp1 -= zrho * x.pap / t.ztp2 * t.zfac1;
+    a_tp1 -= zrho * x.pap * t.rtp2 * t.zfac1;
   }
 
   // D^T: convective component (cloudsc2ad.F90:1501-1526)
@@ -1260,14 +1273,13 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
     real_t zlude = 0.0;
     if (t.llo1) {
       zlude += a_qc;
-      zlude += ((1.0 - t.zclc) / x.lu_k1) * t.zexpl * a_clc;
-      a_lu_k1 -= ((1.0 - t.zclc) * t.zlude / (x.lu_k1 * x.lu_k1)) * t.zexpl * a_clc;
+      zlude += ((1.0 - t.zclc) * t.rlu) * t.zexpl * a_clc;
+      a_lu_k1 -= ((1.0 - t.zclc) * t.zlude * (t.rlu * t.rlu)) * t.zexpl * a_clc;
       a_clc = a_clc * (1.0 - (1.0 - t.zexpl));
     }
     a_lude_in += c->ptsphy * t.zgdp * zlude;
     a_gdp += c->ptsphy * x.lude * zlude;
-    real_t dpk = x.paph_k1 - x.paph_k;
-    real_t g = c->rg * a_gdp / (dpk * dpk);
+    real_t g = c->rg * a_gdp * (t.rdp * t.rdp);
     a_paph_k1 -= g;
     a_paph_k += g;
   }
@@ -1285,17 +1297,12 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
       real_t zqpd = k.zscalm * a_qc * (t.zclc * t.zclc);
       real_t zqcd = (1.0 - k.zscalm) * a_qc * (t.zclc * t.zclc);
       a_clc += (k.zscalm * t.zqpd + (1.0 - k.zscalm) * t.zqcd) * 2.0 * t.zclc * a_qc;
-      if (c->lregcl) {
-        real_t zrat = t.zqpd / t.zqcd;
-        real_t w = 1.0 - k.zscalm * (1.0 - zrat);
-        real_t zyyy = fmin(0.3, 3.5 * sqrt(zrat * (w * w * w)) / (1.0 - k.zscalm));
-        a_clc = zyyy * a_clc;
-      }
-      real_t h = 0.5 / t.zsqrt;
-      zqpd -= h * a_clc / t.zden;
-      zqcd += h * (t.zqpd * a_clc) / (t.zden * t.zden);
-      zqt -= h * (t.zqpd * k.zscalm * a_clc) / (t.zden * t.zden);
-      a_qcrit += h * (t.zqpd * k.zscalm * a_clc) / (t.zden * t.zden);
+      if (c->lregcl) a_clc = regcl_factor(t.zqpd, t.zqcd, k.zscalm) * a_clc;
+      const real_t h = 0.5 * t.rzsqrt, rden2 = t.rden * t.rden;
+      zqpd -= h * a_clc * t.rden;
+      zqcd += h * (t.zqpd * a_clc) * rden2;
+      zqt -= h * (t.zqpd * k.zscalm * a_clc) * rden2;
+      a_qcrit += h * (t.zqpd * k.zscalm * a_clc) * rden2;
       a_qsat += zqcd;
       a_qcrit -= zqcd;
       a_qsat += zqpd;
@@ -1323,15 +1330,15 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
     a_fwat += t.zfacw * zfac;
     real_t zfaci = (1.0 - t.zfwat) * zfac;
     a_fwat -= t.zfaci * zfac;
-    a_tp1 -= 2.0 * c->r5ies * zfaci / (t.tm4i * t.tm4i * t.tm4i);
-    a_tp1 -= 2.0 * c->r5les * zfacw / (t.tm4l * t.tm4l * t.tm4l);
+    a_tp1 -= 2.0 * c->r5ies * zfaci * (t.ri * t.ri * t.ri);
+    a_tp1 -= 2.0 * c->r5les * zfacw * (t.rl * t.rl * t.rl);
     if (t.esdp_clip) zesdp = 0.0;
-    a_foeew += zesdp / x.pap;
-    a_pap -= zesdp * t.zfoeew / (x.pap * x.pap);
-    real_t z3es, z4es, tm4;
-    if (t.cold) { z3es = c->r3ies; z4es = c->r4ies; tm4 = t.tm4i; }
-    else        { z3es = c->r3les; z4es = c->r4les; tm4 = t.tm4l; }
-    a_tp1 += z3es * (c->rtt - z4es) * a_foeew * t.zfoeew / (tm4 * tm4);
+    a_foeew += zesdp * t.zqp;
+    a_pap -= zesdp * t.zfoeew * (t.zqp * t.zqp);
+    real_t z3es, z4es, r4;
+    if (t.cold) { z3es = c->r3ies; z4es = c->r4ies; r4 = t.ri; }
+    else        { z3es = c->r3les; z4es = c->r4les; r4 = t.rl; }
+    a_tp1 += z3es * (c->rtt - z4es) * a_foeew * t.zfoeew * (r4 * r4);
     if (t.cold) a_tp1 += 0.545 * 0.17 * a_fwat * t.zcosh2r;
   }
 
