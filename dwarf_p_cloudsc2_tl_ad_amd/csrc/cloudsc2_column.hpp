@@ -428,75 +428,99 @@ C2_HD void ad_column(long long gcol, AdArgsP a) {
     AdArgsP ap = a;
     C2_LAUNDER(ap);
     in = &ap->in; out = &ap->out;
+    // ---- all loads of this level are issued up front: trajectory inputs, the three checkpointed carries, the output
+    // adjoints, and the OLD values of the 16 input adjoints that are accumulated into at the end.  (Written as
+    // `a[i] += x` after the compute, each read-modify-write would wait for its own HBM round trip: the compiler
+    // cannot move a load above a store that might alias.) ----
     RawLevel cur;
     load_level<HAS_QSAT>(in, o, nproma, nlev, jk, cur);
     const real_t paph_k = in->paph[o.half + d];
+    Carry cy;
+    {
+      const OutPtrs po = *out;
+      cy.rfl = po.fplsl[o.half + d];  // ZRFL5(JK) = PFPLSL5(JK)
+      cy.sfl = po.fplsn[o.half + d];
+    }
+    cy.covptot = scratch[osc + d];
+    const OutPtrs pa = ap->aout;
+    const InPtrsRW px = ap->ain;
+    LevelOut ya;  // output adjoints of this level; enthalpy-flux adjoints folded in below (cloudsc2ad.F90:914-921)
+    ya.tent = pa.tent[oa.loc + d];
+    ya.tenq = pa.tenq[oa.loc + d];
+    ya.tenl = pa.tenl[oa.loc + d];
+    ya.teni = pa.teni[oa.loc + d];
+    ya.clc = pa.clc[oa.full + d];
+    ya.covptot = pa.covptot[oa.full + d];
+    ya.fplsn = pa.fplsn[oa.half + d1];
+    ya.fplsl = pa.fplsl[oa.half + d1];
+    ya.fhpsn = pa.fhpsn[oa.half + d1];
+    ya.fhpsl = pa.fhpsl[oa.half + d1];
+    RawLevel xo;  // old input adjoints (PSUPSAT is assigned, not accumulated: not read)
+    xo.pap = px.pap[oa.full + d];
+    xo.q = px.q[oa.full + d];
+    xo.qsat = px.qsat[oa.full + d];
+    xo.t = px.t[oa.full + d];
+    xo.l = px.l[oa.clv + d];
+    xo.i = px.i[oa.clv + d];
+    xo.lude = px.lude[oa.full + d];
+    xo.mfu = px.mfu[oa.full + d];
+    xo.mfd = px.mfd[oa.full + d];
+    xo.gt = px.gt[oa.cml + d];
+    xo.gq = px.gq[oa.cml + d];
+    xo.gl = px.gl[oa.cml + d];
+    xo.gi = px.gi[oa.cml + d];
+    xo.lu_k1 = last ? 0.0 : px.lu[oa.full + d1];
+    xo.paph_k1 = last ? 0.0 : px.paph[oa.half + d1];
+
     if (!HAS_QSAT) cur.qsat = satur_point<P>(c, cur.pap, cur.t);
     LevelCst k;
     level_cst(tab, jk, last, k);
     LevelIn x;
     make_level_in(cur, paph_k, paph_surf, x);
-    Carry cy;
-    cy.rfl = out->fplsl[o.half + d];  // ZRFL5(JK) = PFPLSL5(JK)
-    cy.sfl = out->fplsn[o.half + d];
-    cy.covptot = scratch[osc + d];
     LevelTraj tr;
     LevelOut lo;
     level_forward<P>(c, k, rh, x, cy, tr, lo);
 
-    // output adjoints of this level; enthalpy-flux adjoints folded in (cloudsc2ad.F90:914-921)
-    C2_LAUNDER(ap);
-    aout = &ap->aout;
-    LevelOut ya;
-    ya.tent = aout->tent[oa.loc + d];
-    ya.tenq = aout->tenq[oa.loc + d];
-    ya.tenl = aout->tenl[oa.loc + d];
-    ya.teni = aout->teni[oa.loc + d];
-    ya.clc = aout->clc[oa.full + d];
-    ya.covptot = aout->covptot[oa.full + d];
-    ya.fplsn = aout->fplsn[oa.half + d1] - aout->fhpsn[oa.half + d1] * c->rlstt;
-    ya.fplsl = aout->fplsl[oa.half + d1] - aout->fhpsl[oa.half + d1] * c->rlvtt;
-
+    ya.fplsn = ya.fplsn - ya.fhpsn * c->rlstt;
+    ya.fplsl = ya.fplsl - ya.fhpsl * c->rlvtt;
     LevelIn ax;
     level_ad(c, k, x, tr, ya, acy, ax);
 
     // accumulate input adjoints (cloudsc2ad.F90:1723-1738; PSUPSAT assigned, :1733)
-    C2_LAUNDER(ap);
-    ain = &ap->ain; aout = &ap->aout;
-    ain->pap[oa.full + d] += ax.pap;
-    ain->q[oa.full + d] += ax.q;
-    ain->qsat[oa.full + d] += ax.qs;
-    ain->t[oa.full + d] += ax.t;
-    ain->l[oa.clv + d] += ax.l;
-    ain->i[oa.clv + d] += ax.i;
-    ain->lude[oa.full + d] += ax.lude;
-    ain->mfu[oa.full + d] += ax.mfu;
-    ain->mfd[oa.full + d] += ax.mfd;
-    ain->gt[oa.cml + d] += ax.gt;
-    ain->gq[oa.cml + d] += ax.gq;
-    ain->gl[oa.cml + d] += ax.gl;
-    ain->gi[oa.cml + d] += ax.gi;
-    ain->supsat[oa.full + d] = ax.supsat;
-    if (!last) ain->lu[oa.full + d1] += ax.lu_k1;
+    px.pap[oa.full + d] = xo.pap + ax.pap;
+    px.q[oa.full + d] = xo.q + ax.q;
+    px.qsat[oa.full + d] = xo.qsat + ax.qs;
+    px.t[oa.full + d] = xo.t + ax.t;
+    px.l[oa.clv + d] = xo.l + ax.l;
+    px.i[oa.clv + d] = xo.i + ax.i;
+    px.lude[oa.full + d] = xo.lude + ax.lude;
+    px.mfu[oa.full + d] = xo.mfu + ax.mfu;
+    px.mfd[oa.full + d] = xo.mfd + ax.mfd;
+    px.gt[oa.cml + d] = xo.gt + ax.gt;
+    px.gq[oa.cml + d] = xo.gq + ax.gq;
+    px.gl[oa.cml + d] = xo.gl + ax.gl;
+    px.gi[oa.cml + d] = xo.gi + ax.gi;
+    px.supsat[oa.full + d] = ax.supsat;
+    if (!last) px.lu[oa.full + d1] = xo.lu_k1 + ax.lu_k1;
     surf_acc += ax.paph_surf;
     if (last) {
       surf_acc += ax.paph_k1;
     } else {
-      ain->paph[oa.half + d1] += ax.paph_k1 + paph_pending;
+      px.paph[oa.half + d1] = xo.paph_k1 + (ax.paph_k1 + paph_pending);
     }
     paph_pending = ax.paph_k;
 
     // output adjoints are consumed (cloudsc2ad.F90:917-919,955-966,1173,1572)
-    aout->tent[oa.loc + d] = 0.0;
-    aout->tenq[oa.loc + d] = 0.0;
-    aout->tenl[oa.loc + d] = 0.0;
-    aout->teni[oa.loc + d] = 0.0;
-    aout->clc[oa.full + d] = 0.0;
-    aout->covptot[oa.full + d] = 0.0;
-    aout->fplsl[oa.half + d1] = 0.0;
-    aout->fplsn[oa.half + d1] = 0.0;
-    aout->fhpsl[oa.half + d1] = 0.0;
-    aout->fhpsn[oa.half + d1] = 0.0;
+    pa.tent[oa.loc + d] = 0.0;
+    pa.tenq[oa.loc + d] = 0.0;
+    pa.tenl[oa.loc + d] = 0.0;
+    pa.teni[oa.loc + d] = 0.0;
+    pa.clc[oa.full + d] = 0.0;
+    pa.covptot[oa.full + d] = 0.0;
+    pa.fplsl[oa.half + d1] = 0.0;
+    pa.fplsn[oa.half + d1] = 0.0;
+    pa.fhpsl[oa.half + d1] = 0.0;
+    pa.fhpsn[oa.half + d1] = 0.0;
   }
   ain = &a->ain; aout = &a->aout;
   ain->paph[oa.half] += paph_pending;
