@@ -189,6 +189,7 @@ C2_HD void level_cst(LevelTabP tab, int jk, bool last, LevelCst& k) {
   k.ceta = tab->lev[jk].ceta;
   k.zscalm = tab->lev[jk].zscalm;
   k.last = last;
+  C2_PIN2(k.ceta, k.zscalm);
 }
 
 // ---------------------------------------------------------------------------------------------------------

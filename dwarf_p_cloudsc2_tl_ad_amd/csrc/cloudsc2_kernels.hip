@@ -146,7 +146,10 @@ int get_tables(const cloudsc2_params& p, const LevelTab** dev, int* kb0, int* kb
 // kernels: thin wrappers around the per-column functions of cloudsc2_column.hpp.  Every kernel has ONE by-value
 // argument block; the device code reads it in place from the kernel-argument segment (scalar cache).
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kBlock = 128;
+#ifndef C2_BLOCK
+#define C2_BLOCK 128
+#endif
+constexpr int kBlock = C2_BLOCK;
 // minimum waves per SIMD requested from the register allocator (0 = let the compiler decide)
 #ifndef C2_NL_WAVES
 #define C2_NL_WAVES 0

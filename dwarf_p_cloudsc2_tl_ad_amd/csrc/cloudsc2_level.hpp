@@ -125,6 +125,10 @@ enum { K4_RTT, K4_R3LES, K4_R4LES, K4_R3IES, K4_R4IES, K4_R2ES, K4_RETV, K4_PTSP
 enum { K5_R5ALVCP, K5_RALVDCP, K5_R5ALSCP, K5_RALSDCP, K5_ZCONS2, K5_ZQTMST, K5_RLVTT, K5_RLSTT };
 // ks: SATUR
 enum { KS_R4LES, KS_R4IES, KS_RTT, KS_R3LES, KS_R3IES, KS_R2ES, KS_RETV, KS_SPARE };
+// kt0..kt2: level_tl / level_ad
+enum { KT0_PTSPHY, KT0_RTT, KT0_R3IES, KT0_R4IES, KT0_R3LES, KT0_R4LES, KT0_R5LES, KT0_R5IES };
+enum { KT1_RETV, KT1_ZCONS3, KT1_RG, KT1_ZQTMST, KT1_ZCONS2, KT1_ZMELTP2, KT1_ZLCRIT_L_R2, KT1_ZLCRIT_I_R2 };
+enum { KT2_CK_L, KT2_CK_I, KT2_RLVTT, KT2_RLSTT, KT2_SPARE0, KT2_SPARE1, KT2_SPARE2, KT2_SPARE3 };
 // kf: FOEALFA
 enum { KF_RTICE, KF_RTWAT, KF_RTWAT_RTICE_R, KF_SPARE0, KF_SPARE1, KF_SPARE2, KF_SPARE3, KF_SPARE4 };
 
@@ -144,6 +148,7 @@ struct Consts {
   real_t zcons2_r;                // PTSPHY*RG = 1/ZCONS2
   // the same values grouped by stage of use (see C2_PIN8); index names below
   StageBlock k0, k1, k2, k3, k4, k5, k6, ks, kf;
+  StageBlock kt0, kt1, kt2;  // constants of level_tl / level_ad
   int evap;                    // LEVAPLS2 .OR. LDRAIN1D
   int lregcl;
   int rvtmp2_zero;
@@ -172,6 +177,14 @@ inline void fill_stage_blocks(Consts& c) {
   k[K5_RLSTT] = c.rlstt;
   k = c.ks.v; k[KS_R4LES] = c.r4les; k[KS_R4IES] = c.r4ies; k[KS_RTT] = c.rtt; k[KS_R3LES] = c.r3les;
   k[KS_R3IES] = c.r3ies; k[KS_R2ES] = c.r2es; k[KS_RETV] = c.retv; k[KS_SPARE] = 0.0;
+  k = c.kt0.v; k[KT0_PTSPHY] = c.ptsphy; k[KT0_RTT] = c.rtt; k[KT0_R3IES] = c.r3ies; k[KT0_R4IES] = c.r4ies;
+  k[KT0_R3LES] = c.r3les; k[KT0_R4LES] = c.r4les; k[KT0_R5LES] = c.r5les; k[KT0_R5IES] = c.r5ies;
+  k = c.kt1.v; k[KT1_RETV] = c.retv; k[KT1_ZCONS3] = c.zcons3; k[KT1_RG] = c.rg; k[KT1_ZQTMST] = c.zqtmst;
+  k[KT1_ZCONS2] = c.zcons2; k[KT1_ZMELTP2] = c.zmeltp2; k[KT1_ZLCRIT_L_R2] = c.zlcrit_l_r * c.zlcrit_l_r;
+  k[KT1_ZLCRIT_I_R2] = c.zlcrit_i_r * c.zlcrit_i_r;
+  // regularised autoconversion coefficients (cloudsc2tl.F90:754-760,794-800)
+  k = c.kt2.v; k[KT2_CK_L] = c.lregcl ? c.zckcodtla : c.zckcodtl; k[KT2_CK_I] = c.lregcl ? c.zckcodtia : c.zckcodti;
+  k[KT2_RLVTT] = c.rlvtt; k[KT2_RLSTT] = c.rlstt; k[KT2_SPARE0] = k[KT2_SPARE1] = k[KT2_SPARE2] = k[KT2_SPARE3] = 0.0;
   k = c.kf.v; k[KF_RTICE] = c.rtice; k[KF_RTWAT] = c.rtwat; k[KF_RTWAT_RTICE_R] = c.rtwat_rtice_r;
   k[KF_SPARE0] = k[KF_SPARE1] = k[KF_SPARE2] = k[KF_SPARE3] = k[KF_SPARE4] = 0.0;
 }
@@ -203,16 +216,41 @@ typedef const C2_CONST_AS Consts* ConstsP;
 // uses them into 64-byte blocks; a stage copies its block with ONE s_load_dwordx16 and pins it (C2_PIN8), i.e. one
 // wait per stage, and the SGPRs are free again afterwards.
 #if defined(__HIP_DEVICE_COMPILE__)
+// C2_PIN_DEF=0: "s" inputs -- the values stay rematerialisable: under SGPR pressure the allocator re-issues the s_load
+// inside divergent branches (one more exposed wait each) instead of spilling.  C2_PIN_DEF=1: "+s" -- the values become
+// definitions of the asm statement and are parked in VGPR lanes under pressure (v_readlane at the use, no wait).
+// Which is faster is kernel-specific and was measured: 0 for NL, 1 for TL and AD.
+#ifndef C2_PIN_DEF
+#define C2_PIN_DEF 0
+#endif
+#if C2_PIN_DEF
+#define C2_PIN8(b) asm volatile("" : "+s"((b).v[0]), "+s"((b).v[1]), "+s"((b).v[2]), "+s"((b).v[3]), "+s"((b).v[4]), \
+                                 "+s"((b).v[5]), "+s"((b).v[6]), "+s"((b).v[7]))
+#define C2_PIN2(x, y) asm volatile("" : "+s"(x), "+s"(y))
+#else
 #define C2_PIN8(b) asm volatile("" ::"s"((b).v[0]), "s"((b).v[1]), "s"((b).v[2]), "s"((b).v[3]), "s"((b).v[4]), "s"((b).v[5]), \
                                  "s"((b).v[6]), "s"((b).v[7]))
+#define C2_PIN2(x, y) asm volatile("" ::"s"(x), "s"(y))
+#endif
 #else
 #define C2_PIN8(b) ((void)0)
+#define C2_PIN2(x, y) ((void)0)
 #endif
 template <class B>
 C2_HD B c2_block(const C2_CONST_AS B* p) {
   B b = *p;
   C2_PIN8(b);
   return b;
+}
+// three blocks with one wait
+template <class B>
+C2_HD void c2_block3(const C2_CONST_AS B* p, const C2_CONST_AS B* q, const C2_CONST_AS B* r, B& a, B& b, B& cc) {
+  a = *p;
+  b = *q;
+  cc = *r;
+  C2_PIN8(a);
+  C2_PIN8(b);
+  C2_PIN8(cc);
 }
 // two blocks with one wait: both loads are issued before the first pin
 template <class B>
@@ -748,30 +786,44 @@ C2_HD real_t regcl_factor(real_t zqpd5, real_t zqcd5, real_t zscalm) {
 // ---------------------------------------------------------------------------------------------------------
 C2_HD void level_tl(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelTraj& t, const LevelIn& dx,
                     Carry& dcy, LevelOut& dout) {
+  // constants of this function from three 64-byte blocks (one scalar-cache wait)
+  StageBlock kt0, kt1, kt2;
+  c2_block3(&c->kt0, &c->kt1, &c->kt2, kt0, kt1, kt2);
+  const real_t ptsphy = kt0.v[KT0_PTSPHY], rtt = kt0.v[KT0_RTT], r3ies = kt0.v[KT0_R3IES], r4ies = kt0.v[KT0_R4IES],
+               r3les = kt0.v[KT0_R3LES], r4les = kt0.v[KT0_R4LES], r5les = kt0.v[KT0_R5LES], r5ies = kt0.v[KT0_R5IES];
+  const real_t retv = kt1.v[KT1_RETV], zcons3 = kt1.v[KT1_ZCONS3], rg = kt1.v[KT1_RG], zqtmst = kt1.v[KT1_ZQTMST],
+               zcons2 = kt1.v[KT1_ZCONS2], zmeltp2 = kt1.v[KT1_ZMELTP2], zlcrit_l_r2 = kt1.v[KT1_ZLCRIT_L_R2],
+               zlcrit_i_r2 = kt1.v[KT1_ZLCRIT_I_R2];
+  const real_t ck_l = kt2.v[KT2_CK_L], ck_i = kt2.v[KT2_CK_I];
+  const int lregcl = c->lregcl, rvtmp2_zero = c->rvtmp2_zero;
+  (void)r4ies; (void)r4les; (void)zcons3; (void)zmeltp2; (void)rvtmp2_zero;
   // first guess
-  real_t ztp1 = dx.t + c->ptsphy * dx.gt;
-  real_t zqp1 = dx.q + c->ptsphy * dx.gq + dx.supsat;
-  real_t zl = dx.l + c->ptsphy * dx.gl;
-  real_t zi = dx.i + c->ptsphy * dx.gi;
+  real_t ztp1 = dx.t + ptsphy * dx.gt;
+  real_t zqp1 = dx.q + ptsphy * dx.gq + dx.supsat;
+  real_t zl = dx.l + ptsphy * dx.gl;
+  real_t zi = dx.i + ptsphy * dx.gi;
   real_t zdp = dx.paph_k1 - dx.paph_k;
-  real_t zzz = c->rvtmp2_zero ? 0.0 : -c->rcpd * c->rvtmp2 * zqp1 * (t.zzz * t.zzz);
-  real_t zlfdcp = c->rlmlt * zzz, zlsdcp = c->rlstt * zzz, zlvdcp = c->rlvtt * zzz;
+  real_t zlfdcp = 0.0, zlsdcp = 0.0, zlvdcp = 0.0;
+  if (!rvtmp2_zero) {  // cloudsc2tl.F90:366-373
+    real_t zzz = -c->rcpd * c->rvtmp2 * zqp1 * (t.zzz * t.zzz);
+    zlfdcp = c->rlmlt * zzz; zlsdcp = c->rlstt * zzz; zlvdcp = c->rlvtt * zzz;
+  }
 
   // A (cloudsc2tl.F90:463-501)
   // quotients of the reference are products with the trajectory's reciprocals (LevelTraj::rl, ri, zqp, rdp, ...)
   real_t zfwat, z3es, z4es, r4;
-  if (t.cold) { zfwat = 0.545 * 0.17 * ztp1 * t.zcosh2r; z3es = c->r3ies; z4es = c->r4ies; r4 = t.ri; }
-  else        { zfwat = 0.0;                            z3es = c->r3les; z4es = c->r4les; r4 = t.rl; }
+  if (t.cold) { zfwat = 0.545 * 0.17 * ztp1 * t.zcosh2r; z3es = r3ies; z4es = r4ies; r4 = t.ri; }
+  else        { zfwat = 0.0;                            z3es = r3les; z4es = r4les; r4 = t.rl; }
   const real_t rp = t.zqp;
-  real_t zfoeew = z3es * (c->rtt - z4es) * ztp1 * t.zfoeew * (r4 * r4);
+  real_t zfoeew = z3es * (rtt - z4es) * ztp1 * t.zfoeew * (r4 * r4);
   real_t zesdp = zfoeew * rp - dx.pap * t.zfoeew * (rp * rp);
   if (t.esdp_clip) zesdp = 0.0;
-  real_t zfacw = -2.0 * c->r5les * ztp1 * (t.rl * t.rl * t.rl);
-  real_t zfaci = -2.0 * c->r5ies * ztp1 * (t.ri * t.ri * t.ri);
+  real_t zfacw = -2.0 * r5les * ztp1 * (t.rl * t.rl * t.rl);
+  real_t zfaci = -2.0 * r5ies * ztp1 * (t.ri * t.ri * t.ri);
   real_t zfac = t.zfwat * zfacw + t.zfacw * zfwat + (1.0 - t.zfwat) * zfaci - t.zfaci * zfwat;
-  real_t zcor = c->retv * zesdp * (t.zcor * t.zcor);
+  real_t zcor = retv * zesdp * (t.zcor * t.zcor);
   real_t zdqsdtemp = t.zfac * t.zcor * dx.qs + t.zfac * x.qs * zcor + t.zcor * x.qs * zfac;
-  real_t zcorqs = c->zcons3 * zdqsdtemp;
+  real_t zcorqs = zcons3 * zdqsdtemp;
   real_t zqlim = t.qlim_is_qs ? dx.qs : zqp1;
 
   // B (cloudsc2tl.F90:532-543)
@@ -790,15 +842,15 @@ C2_HD void level_tl(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
     real_t zqpd = zqsat - zqt;
     real_t zqcd = zqsat - zqcrit;
     pclc = -(0.5 * t.rzsqrt) * (zqpd * t.zden - t.zqpd * (zqcd - k.zscalm * (zqt - zqcrit))) * (t.rden * t.rden);
-    if (c->lregcl) pclc = regcl_factor(t.zqpd, t.zqcd, k.zscalm) * pclc;
+    if (lregcl) pclc = regcl_factor(t.zqpd, t.zqcd, k.zscalm) * pclc;
     zqc = (k.zscalm * zqpd + (1.0 - k.zscalm) * zqcd) * (t.zclc * t.zclc) +
           (k.zscalm * t.zqpd + (1.0 - k.zscalm) * t.zqcd) * 2.0 * t.zclc * pclc;
   }
 
   // D (cloudsc2tl.F90:595-622)
   const real_t rdp2 = t.rdp * t.rdp;
-  real_t zgdp = -c->rg * (dx.paph_k1 - dx.paph_k) * rdp2;
-  real_t zlude = c->ptsphy * t.zgdp * dx.lude + c->ptsphy * x.lude * zgdp;
+  real_t zgdp = -rg * (dx.paph_k1 - dx.paph_k) * rdp2;
+  real_t zlude = ptsphy * t.zgdp * dx.lude + ptsphy * x.lude * zgdp;
   if (t.llo1) {
     pclc = pclc - pclc * (1.0 - t.zexpl) + ((1.0 - t.zclc) * t.rlu) * t.zexpl * zlude -
            ((1.0 - t.zclc) * t.zlude * (t.rlu * t.rlu)) * t.zexpl * dx.lu_k1;
@@ -808,15 +860,15 @@ C2_HD void level_tl(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
   // E (cloudsc2tl.F90:628-664)
   {
     real_t zrho = (dx.pap - ztp1 * x.pap * t.rtp2) * t.zfac1;
-    real_t zrodqsdp = (-zrho * x.qs - t.zrho * dx.qs + t.zrho * x.qs * (dx.pap - c->retv * zfoeew) * t.zfac2) * t.zfac2;
+    real_t zrodqsdp = (-zrho * x.qs - t.zrho * dx.qs + t.zrho * x.qs * (dx.pap - retv * zfoeew) * t.zfac2) * t.zfac2;
     real_t zldcp = zfwat * t.zlvdcp + t.zfwat * zlvdcp + (1.0 - t.zfwat) * zlsdcp - zfwat * t.zlsdcp;
-    real_t dtdzmo = -(c->rg * (zldcp * t.zrodqsdp + t.zldcp * zrodqsdp) +
+    real_t dtdzmo = -(rg * (zldcp * t.zrodqsdp + t.zldcp * zrodqsdp) +
                       t.dtdzmo * (t.zldcp * zdqsdtemp + zldcp * t.zdqsdtemp)) * t.zfac3;
-    real_t zdqsdz = t.zdqsdtemp * dtdzmo + zdqsdtemp * t.dtdzmo - c->rg * zrodqsdp;
+    real_t zdqsdz = t.zdqsdtemp * dtdzmo + zdqsdtemp * t.dtdzmo - rg * zrodqsdp;
     real_t zdqc;
     if (t.llo3) {
-      zdqc = (c->ptsphy * (zdqsdz * (x.mfu + x.mfd) + t.zdqsdz * (dx.mfu + dx.mfd)) - t.zdqc * zrho) * t.zfac4;
-      if (c->lregcl) zdqc = zdqc * 0.1;
+      zdqc = (ptsphy * (zdqsdz * (x.mfu + x.mfd) + t.zdqsdz * (dx.mfu + dx.mfd)) - t.zdqc * zrho) * t.zfac4;
+      if (lregcl) zdqc = zdqc * 0.1;
     } else {
       zdqc = zqc;
     }
@@ -826,8 +878,8 @@ C2_HD void level_tl(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
   // F (cloudsc2tl.F90:670-680)
   real_t zqlwc = zqc * t.zfwat + t.zqc3 * zfwat;
   real_t zqiwc = zqc * (1.0 - t.zfwat) - t.zqc3 * zfwat;
-  real_t zcondl = (zqlwc - zl) * c->zqtmst;
-  real_t zcondi = (zqiwc - zi) * c->zqtmst;
+  real_t zcondl = (zqlwc - zl) * zqtmst;
+  real_t zcondi = (zqiwc - zi) * zqtmst;
 
   // G (cloudsc2tl.F90:687-696)
   real_t zcovptot = t.newmax ? pclc : dcy.covptot;
@@ -837,8 +889,8 @@ C2_HD void level_tl(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
   // H (cloudsc2tl.F90:704-733)
   real_t zrfln, zsfln;
   if (t.melt) {
-    real_t zcons = c->zcons2 * (zdp * t.zlfdcp - t.zdp * zlfdcp) * (t.rlfdcp * t.rlfdcp);
-    real_t zz2s = t.warm2 ? (t.zcons * ztp1 + zcons * (t.ztp2 - c->zmeltp2)) : 0.0;
+    real_t zcons = zcons2 * (zdp * t.zlfdcp - t.zdp * zlfdcp) * (t.rlfdcp * t.rlfdcp);
+    real_t zz2s = t.warm2 ? (t.zcons * ztp1 + zcons * (t.ztp2 - zmeltp2)) : 0.0;
     real_t zsnmlt = t.melt_all ? dcy.sfl : zz2s;
     zrfln = dcy.rfl + zsnmlt;
     zsfln = dcy.sfl - zsnmlt;
@@ -853,23 +905,23 @@ C2_HD void level_tl(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
   if (t.cloudy) {
     const real_t rclc2 = t.rclc * t.rclc;
     real_t zcldl = zqlwc * t.rclc - t.zqlwc1 * pclc * rclc2;
-    real_t ck = c->lregcl ? c->zckcodtla : c->zckcodtl;
-    real_t zd = (2.0 * ck * (c->zlcrit_l_r * c->zlcrit_l_r)) * t.zexp3 * t.zcldl * zcldl;
+    real_t ck = ck_l;
+    real_t zd = (2.0 * ck * zlcrit_l_r2) * t.zexp3 * t.zcldl * zcldl;
     real_t zlnew = t.zcldl * t.zexpdl * pclc + t.clc * t.zexpdl * zcldl - t.clc * t.zcldl * t.zexpdl * zd;
     zprr = zqlwc - zlnew;
     zqlwc = zqlwc - zprr;
 
     real_t zcldi = zqiwc * t.rclc - t.zqiwc1 * pclc * rclc2;
-    real_t cki = c->lregcl ? c->zckcodtia : c->zckcodti;
+    real_t cki = ck_i;
     real_t zdi = cki * t.zexp1 *
-                 (t.zexp2 * (2.0 * t.zcldi * zcldi * (c->zlcrit_i_r * c->zlcrit_i_r) - 0.025 * ztp1) + 0.025 * ztp1);
+                 (t.zexp2 * (2.0 * t.zcldi * zcldi * zlcrit_i_r2 - 0.025 * ztp1) + 0.025 * ztp1);
     real_t zinew = t.zcldi * t.zexpdi * pclc + t.clc * t.zexpdi * zcldi - t.clc * t.zcldi * t.zexpdi * zdi;
     zprs = zqiwc - zinew;
     zqiwc = zqiwc - zprs;
   }
-  real_t zdr = c->zcons2 * (t.zdp * (zprr + zprs) + zdp * (t.zprr + t.zprs));
+  real_t zdr = zcons2 * (t.zdp * (zprr + zprs) + zdp * (t.zprr + t.zprs));
   real_t zrfreeze = 0.0;
-  if (t.frz1) zrfreeze = c->zcons2 * (zdp * t.zprr + t.zdp * zprr);
+  if (t.frz1) zrfreeze = zcons2 * (zdp * t.zprr + t.zdp * zprr);
   zrfln = zrfln + t.zfwatr1 * zdr;
   zsfln = zsfln + (1.0 - t.zfwatr1) * zdr;
 
@@ -882,15 +934,15 @@ C2_HD void level_tl(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
     real_t omc2 = t.omc * t.omc;
     real_t zqe = dx.qs - ((x.qs - t.zqlim) * zcovpclr + t.covpclr * dx.qs - t.covpclr * zqlim) / omc2 -
                  2.0 * (x.qs - t.zqlim) * t.covpclr * pclc / (omc2 * t.omc);
-    real_t zbeta = 0.5777 * (c->rg * c->rpecons / 5.09e-3) *
+    real_t zbeta = 0.5777 * (rg * c->rpecons / 5.09e-3) *
                    pow(5.09e-3 * t.covpclr / (t.zpreclr1 * t.zsqp), 0.4223) *
                    ((t.zsqp * zpreclr + 0.5 * t.zpreclr1 * dx.pap / sqrt(x.pap * x.paph_surf) -
                      0.5 * t.zpreclr1 * t.zsqp * dx.paph_surf / x.paph_surf) / t.covpclr -
                     t.zpreclr1 * t.zsqp * zcovpclr / (t.covpclr * t.covpclr));
-    real_t den = 1.0 + t.zbeta * c->ptsphy * t.zcorqs;
-    real_t zb = c->ptsphy * ((x.qs - t.zqe) * zbeta + t.zbeta * dx.qs - t.zbeta * zqe) / den -
-                (c->ptsphy * c->ptsphy) * t.zbeta * (x.qs - t.zqe) * (t.zbeta * zcorqs + t.zcorqs * zbeta) / (den * den);
-    real_t zdtgdp = -c->ptsphy * c->rg * (dx.paph_k1 - dx.paph_k) * rdp2;
+    real_t den = 1.0 + t.zbeta * ptsphy * t.zcorqs;
+    real_t zb = ptsphy * ((x.qs - t.zqe) * zbeta + t.zbeta * dx.qs - t.zbeta * zqe) / den -
+                (ptsphy * ptsphy) * t.zbeta * (x.qs - t.zqe) * (t.zbeta * zcorqs + t.zcorqs * zbeta) / (den * den);
+    real_t zdtgdp = -ptsphy * rg * (dx.paph_k1 - dx.paph_k) * rdp2;
     real_t zdpr = (t.covpclr * zb + t.zb * zcovpclr) / t.zdtgdp - t.covpclr * t.zb * zdtgdp / (t.zdtgdp * t.zdtgdp);
     if (t.dpr_clip) zdpr = zpreclr;
     zpreclr = zpreclr - zdpr;
@@ -913,8 +965,8 @@ C2_HD void level_tl(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
                     (t.zlsdcp - t.zlvdcp) * zrfreeze) * t.zgdp -
                    (t.zlvdcp * t.zevapr + t.zlsdcp * t.zevaps + x.lude * w5 -
                     (t.zlsdcp - t.zlvdcp) * t.zrfreeze1) * zgdp;
-    ztp1 = ztp1 + c->ptsphy * zdtdt;
-    zqp1 = zqp1 + c->ptsphy * zdqdt;
+    ztp1 = ztp1 + ptsphy * zdtdt;
+    zqp1 = zqp1 + ptsphy * zdqdt;
   }
   real_t zqold = zqp1;
 
@@ -924,10 +976,10 @@ C2_HD void level_tl(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const real_t r4a = t.a_rtm4[it], r4a2 = r4a * r4a;
-      real_t dfoeew = t.z3es * (c->rtt - t.z4es) * ztp1 * t.a_foeew[it] * r4a2;
+      real_t dfoeew = t.z3es * (rtt - t.z4es) * ztp1 * t.a_foeew[it] * r4a2;
       real_t dqsat = t.zqp * dfoeew + zqp * t.a_foeew[it];
       if (t.a_clip[it]) dqsat = 0.0;
-      real_t dcor = (c->retv * dqsat) * (t.a_cor[it] * t.a_cor[it]);
+      real_t dcor = (retv * dqsat) * (t.a_cor[it] * t.a_cor[it]);
       dqsat = t.a_qsatu[it] * dcor + dqsat * t.a_cor[it];
       real_t dz2s = -2.0 * ztp1 * t.z5alcp * (r4a2 * r4a);
       const real_t rden = t.a_rden[it];
@@ -945,13 +997,13 @@ C2_HD void level_tl(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
     real_t zdq = 0.0;
     if (t.dq_pos) {
       zdq = zqold - zqp1;
-      if (c->lregcl) zdq = zdq * 0.7;
+      if (lregcl) zdq = zdq * 0.7;
     }
-    real_t zdr2 = c->zcons2 * (t.zdp * zdq + t.zdq * zdp);
+    real_t zdr2 = zcons2 * (t.zdp * zdq + t.zdq * zdp);
     real_t zrfreeze2 = 0.0;
     if (t.frz2) zrfreeze2 = zfwat * t.zdr2 + t.zfwat * zdr2;
-    zcondl = zcondl + (t.zfwatr2 * zdq) * c->zqtmst;
-    zcondi = zcondi + ((1.0 - t.zfwatr2) * zdq) * c->zqtmst;
+    zcondl = zcondl + (t.zfwatr2 * zdq) * zqtmst;
+    zcondi = zcondi + ((1.0 - t.zfwatr2) * zdq) * zqtmst;
     zrfln = zrfln + t.zfwatr2 * zdr2;
     zsfln = zsfln + (1.0 - t.zfwatr2) * zdr2;
     zrfreeze = zrfreeze + zrfreeze2;
@@ -963,14 +1015,14 @@ C2_HD void level_tl(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
                  (t.zlsdcp - t.zlvdcp) * zrfreeze) * t.zgdp -
                 (t.zlvdcp * t.zevapr + t.zlsdcp * t.zevaps + x.lude * w5 -
                  (t.zlsdcp - t.zlvdcp) * t.zrfreeze3) * zgdp;
-    dout.tenl = (zqlwc - zl) * c->zqtmst;
-    dout.teni = (zqiwc - zi) * c->zqtmst;
+    dout.tenl = (zqlwc - zl) * zqtmst;
+    dout.teni = (zqiwc - zi) * zqtmst;
     dout.clc = pclc;
     dout.covptot = pcovptot;
     dout.fplsl = zrfln;
     dout.fplsn = zsfln;
-    dout.fhpsl = -zrfln * c->rlvtt;  // cloudsc2tl.F90:1108-1111
-    dout.fhpsn = -zsfln * c->rlstt;
+    dout.fhpsl = -zrfln * kt2.v[KT2_RLVTT];  // cloudsc2tl.F90:1108-1111
+    dout.fhpsn = -zsfln * kt2.v[KT2_RLSTT];
   }
 
   dcy.rfl = zrfln;
@@ -990,6 +1042,17 @@ C2_HD void level_tl(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
 // ---------------------------------------------------------------------------------------------------------
 C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelTraj& t, const LevelOut& ya,
                     Carry& acy, LevelIn& ax) {
+  // constants of this function from three 64-byte blocks (one scalar-cache wait)
+  StageBlock kt0, kt1, kt2;
+  c2_block3(&c->kt0, &c->kt1, &c->kt2, kt0, kt1, kt2);
+  const real_t ptsphy = kt0.v[KT0_PTSPHY], rtt = kt0.v[KT0_RTT], r3ies = kt0.v[KT0_R3IES], r4ies = kt0.v[KT0_R4IES],
+               r3les = kt0.v[KT0_R3LES], r4les = kt0.v[KT0_R4LES], r5les = kt0.v[KT0_R5LES], r5ies = kt0.v[KT0_R5IES];
+  const real_t retv = kt1.v[KT1_RETV], zcons3 = kt1.v[KT1_ZCONS3], rg = kt1.v[KT1_RG], zqtmst = kt1.v[KT1_ZQTMST],
+               zcons2 = kt1.v[KT1_ZCONS2], zmeltp2 = kt1.v[KT1_ZMELTP2], zlcrit_l_r2 = kt1.v[KT1_ZLCRIT_L_R2],
+               zlcrit_i_r2 = kt1.v[KT1_ZLCRIT_I_R2];
+  const real_t ck_l = kt2.v[KT2_CK_L], ck_i = kt2.v[KT2_CK_I];
+  const int lregcl = c->lregcl, rvtmp2_zero = c->rvtmp2_zero;
+  (void)r4ies; (void)r4les; (void)zcons3; (void)zmeltp2; (void)rvtmp2_zero;
   // adjoints of level-local quantities
   real_t a_tp1 = 0.0, a_qp1 = 0.0, a_l = 0.0, a_i = 0.0, a_dp = 0.0;
   real_t a_lvdcp = 0.0, a_lsdcp = 0.0, a_lfdcp = 0.0;
@@ -1008,8 +1071,8 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
   // M^T: final tendencies (cloudsc2ad.F90:959-1012)
   {
     real_t zdidt = ya.teni, zdldt = ya.tenl, zdtdt = ya.tent, zdqdt = ya.tenq;
-    a_i -= c->zqtmst * zdidt;  a_qiwc += c->zqtmst * zdidt;
-    a_l -= c->zqtmst * zdldt;  a_qlwc += c->zqtmst * zdldt;
+    a_i -= zqtmst * zdidt;  a_qiwc += zqtmst * zdidt;
+    a_l -= zqtmst * zdldt;  a_qlwc += zqtmst * zdldt;
     a_gdp -= zdtdt * (t.zlvdcp * t.zevapr + t.zlsdcp * t.zevaps + x.lude * w5 - (t.zlsdcp - t.zlvdcp) * t.zrfreeze3);
     a_condl += zdtdt * t.zlvdcp;
     a_condi += zdtdt * t.zlsdcp;
@@ -1037,16 +1100,16 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
   {
     real_t zrfreeze2 = a_rfreeze;
     real_t zsn = a_sfln, zrn = a_rfln;
-    real_t a_dq = a_condi * (1.0 - t.zfwatr2) * c->zqtmst + a_condl * t.zfwatr2 * c->zqtmst;
+    real_t a_dq = a_condi * (1.0 - t.zfwatr2) * zqtmst + a_condl * t.zfwatr2 * zqtmst;
     real_t zdr2 = (1.0 - t.zfwatr2) * zsn + t.zfwatr2 * zrn;
     if (t.frz2) {
       a_fwat += t.zdr2 * zrfreeze2;
       zdr2 += t.zfwat * zrfreeze2;
     }
-    a_dq += c->zcons2 * t.zdp * zdr2;
-    a_dp += c->zcons2 * t.zdq * zdr2;
+    a_dq += zcons2 * t.zdp * zdr2;
+    a_dp += zcons2 * t.zdq * zdr2;
     if (t.dq_pos) {
-      if (c->lregcl) a_dq *= 0.7;
+      if (lregcl) a_dq *= 0.7;
       a_qold += a_dq;
       a_qp1 -= a_dq;
     }
@@ -1069,11 +1132,11 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
       real_t ztarg = -2.0 * z2s * t.z5alcp * (r4a2 * r4a);
       zcor += zqsat * t.a_qsatu[it];
       zqsat = zqsat * t.a_cor[it];
-      zqsat += zcor * c->retv * (t.a_cor[it] * t.a_cor[it]);
+      zqsat += zcor * retv * (t.a_cor[it] * t.a_cor[it]);
       if (t.a_clip[it]) zqsat = 0.0;
       real_t zfoeew = zqsat * t.zqp;
       a_zqp += zqsat * t.a_foeew[it];
-      ztarg += zfoeew * t.z3es * (c->rtt - t.z4es) * t.a_foeew[it] * r4a2;
+      ztarg += zfoeew * t.z3es * (rtt - t.z4es) * t.a_foeew[it] * r4a2;
       a_tp1 += ztarg;
     }
     a_pap -= a_zqp * (t.zqp * t.zqp);
@@ -1082,8 +1145,8 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
   // K^T: first-guess T and q (cloudsc2ad.F90:1076-1125)
   {
     a_qp1 += a_qold;
-    real_t zdqdt = c->ptsphy * a_qp1;
-    real_t zdtdt = c->ptsphy * a_tp1;
+    real_t zdqdt = ptsphy * a_qp1;
+    real_t zdtdt = ptsphy * a_tp1;
     a_gdp -= zdtdt * (t.zlvdcp * t.zevapr + t.zlsdcp * t.zevaps + x.lude * w5 - (t.zlsdcp - t.zlvdcp) * t.zrfreeze1);
     a_condl += zdtdt * t.zlvdcp;
     a_condi += zdtdt * t.zlsdcp;
@@ -1129,19 +1192,19 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
     a_covpclr += t.zb * zdpr / t.zdtgdp;
     a_dtgdp -= t.covpclr * t.zb * zdpr / (t.zdtgdp * t.zdtgdp);
     {
-      real_t g = c->ptsphy * c->rg * a_dtgdp * (t.rdp * t.rdp);
+      real_t g = ptsphy * rg * a_dtgdp * (t.rdp * t.rdp);
       a_paph_k1 -= g;
       a_paph_k += g;
     }
     // implicit solution
-    real_t den = 1.0 + t.zbeta * c->ptsphy * t.zcorqs;
-    zbeta += c->ptsphy * (x.qs - t.zqe) * zb / den;
-    a_qs += c->ptsphy * t.zbeta * zb / den;
-    zqe -= c->ptsphy * t.zbeta * zb / den;
-    a_corqs -= (c->ptsphy * c->ptsphy) * t.zbeta * (x.qs - t.zqe) * t.zbeta * zb / (den * den);
-    zbeta -= (c->ptsphy * c->ptsphy) * t.zbeta * (x.qs - t.zqe) * t.zcorqs * zb / (den * den);
+    real_t den = 1.0 + t.zbeta * ptsphy * t.zcorqs;
+    zbeta += ptsphy * (x.qs - t.zqe) * zb / den;
+    a_qs += ptsphy * t.zbeta * zb / den;
+    zqe -= ptsphy * t.zbeta * zb / den;
+    a_corqs -= (ptsphy * ptsphy) * t.zbeta * (x.qs - t.zqe) * t.zbeta * zb / (den * den);
+    zbeta -= (ptsphy * ptsphy) * t.zbeta * (x.qs - t.zqe) * t.zcorqs * zb / (den * den);
     // zbeta
-    real_t zxx = 0.5777 * (c->rg * c->rpecons / 5.09e-3) * pow(5.09e-3 * t.covpclr / (t.zpreclr1 * t.zsqp), 0.4223);
+    real_t zxx = 0.5777 * (rg * c->rpecons / 5.09e-3) * pow(5.09e-3 * t.covpclr / (t.zpreclr1 * t.zsqp), 0.4223);
     zpreclr += zxx * t.zsqp * zbeta / t.covpclr;
     a_pap += (zxx * 0.5 * t.zpreclr1 * zbeta / sqrt(x.pap * x.paph_surf)) / t.covpclr;
     a_paph_surf -= (zxx * 0.5 * t.zpreclr1 * t.zsqp * zbeta / x.paph_surf) / t.covpclr;
@@ -1168,12 +1231,12 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
     real_t zdr = (1.0 - t.zfwatr1) * a_sfln + t.zfwatr1 * a_rfln;
     real_t zprr = 0.0, zprs = 0.0;
     if (t.frz1) {
-      a_dp += a_rfreeze * c->zcons2 * t.zprr;
-      zprr += a_rfreeze * c->zcons2 * t.zdp;
+      a_dp += a_rfreeze * zcons2 * t.zprr;
+      zprr += a_rfreeze * zcons2 * t.zdp;
     }
-    zprr += c->zcons2 * t.zdp * zdr;
-    zprs += c->zcons2 * t.zdp * zdr;
-    a_dp += c->zcons2 * (t.zprr + t.zprs) * zdr;
+    zprr += zcons2 * t.zdp * zdr;
+    zprs += zcons2 * t.zdp * zdr;
+    a_dp += zcons2 * (t.zprr + t.zprs) * zdr;
     if (t.cloudy) {
       // ice
       zprs -= a_qiwc;
@@ -1182,9 +1245,9 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
       a_clc += zinew * t.zcldi * t.zexpdi;
       real_t zcldi = zinew * t.clc * t.zexpdi;
       real_t zdi = -zinew * t.clc * t.zcldi * t.zexpdi;
-      real_t cki = c->lregcl ? c->zckcodtia : c->zckcodti;
+      real_t cki = ck_i;
       a_tp1 += cki * t.zexp1 * (1.0 - t.zexp2) * 0.025 * zdi;
-      zcldi += (cki * t.zexp1 * t.zexp2 * 2.0 * t.zcldi * (c->zlcrit_i_r * c->zlcrit_i_r)) * zdi;
+      zcldi += (cki * t.zexp1 * t.zexp2 * 2.0 * t.zcldi * zlcrit_i_r2) * zdi;
       a_qiwc += zcldi * t.rclc;
       a_clc -= t.zqiwc1 * zcldi * (t.rclc * t.rclc);
       // liquid
@@ -1194,8 +1257,8 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
       a_clc += zlnew * t.zcldl * t.zexpdl;
       real_t zcldl = zlnew * t.clc * t.zexpdl;
       real_t zdl = -zlnew * t.clc * t.zcldl * t.zexpdl;
-      real_t ck = c->lregcl ? c->zckcodtla : c->zckcodtl;
-      zcldl += (2.0 * ck * (c->zlcrit_l_r * c->zlcrit_l_r)) * t.zexp3 * t.zcldl * zdl;
+      real_t ck = ck_l;
+      zcldl += (2.0 * ck * zlcrit_l_r2) * t.zexp3 * t.zcldl * zdl;
       a_qlwc += zcldl * t.rclc;
       a_clc -= t.zqlwc1 * zcldl * (t.rclc * t.rclc);
     }
@@ -1214,10 +1277,10 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
     if (t.melt_all) a_sfl += zsnmlt; else zz2s += zsnmlt;
     if (t.warm2) {
       a_tp1 += t.zcons * zz2s;
-      zcons += (t.ztp2 - c->zmeltp2) * zz2s;
+      zcons += (t.ztp2 - zmeltp2) * zz2s;
     }
-    a_dp += c->zcons2 * zcons * t.rlfdcp;
-    a_lfdcp -= c->zcons2 * t.zdp * zcons * (t.rlfdcp * t.rlfdcp);
+    a_dp += zcons2 * zcons * t.rlfdcp;
+    a_lfdcp -= zcons2 * t.zdp * zcons * (t.rlfdcp * t.rlfdcp);
   } else {
     a_sfl += a_sfln;
     a_rfl += a_rfln;
@@ -1231,8 +1294,8 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
 
   // F^T (cloudsc2ad.F90:1425-1441)
   real_t a_qc = 0.0;
-  a_qiwc += a_condi * c->zqtmst;  a_i -= a_condi * c->zqtmst;
-  a_qlwc += a_condl * c->zqtmst;  a_l -= a_condl * c->zqtmst;
+  a_qiwc += a_condi * zqtmst;  a_i -= a_condi * zqtmst;
+  a_qlwc += a_condl * zqtmst;  a_l -= a_condl * zqtmst;
   a_qc += a_qiwc * (1.0 - t.zfwat);
   a_fwat -= a_qiwc * t.zqc3;
   a_qc += a_qlwc * t.zfwat;
@@ -1243,19 +1306,19 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
   {
     real_t zdqc = -a_qc, zdqsdz = 0.0, zrho = 0.0;
     if (t.llo3) {
-      if (c->lregcl) zdqc *= 0.1;
-      zdqsdz += zdqc * c->ptsphy * (x.mfu + x.mfd) * t.zfac4;
-      a_mfu += zdqc * c->ptsphy * t.zdqsdz * t.zfac4;
-      a_mfd += zdqc * c->ptsphy * t.zdqsdz * t.zfac4;
+      if (lregcl) zdqc *= 0.1;
+      zdqsdz += zdqc * ptsphy * (x.mfu + x.mfd) * t.zfac4;
+      a_mfu += zdqc * ptsphy * t.zdqsdz * t.zfac4;
+      a_mfd += zdqc * ptsphy * t.zdqsdz * t.zfac4;
       zrho -= zdqc * t.zdqc * t.zfac4;
     } else {
       a_qc += zdqc;
     }
     real_t dtdzmo = zdqsdz * t.zdqsdtemp;
     a_dqsdtemp += zdqsdz * t.dtdzmo;
-    real_t zrodqsdp = -zdqsdz * c->rg;
-    real_t zldcp = -dtdzmo * (c->rg * t.zrodqsdp + t.dtdzmo * t.zdqsdtemp) * t.zfac3;
-    zrodqsdp -= dtdzmo * c->rg * t.zldcp * t.zfac3;
+    real_t zrodqsdp = -zdqsdz * rg;
+    real_t zldcp = -dtdzmo * (rg * t.zrodqsdp + t.dtdzmo * t.zdqsdtemp) * t.zfac3;
+    zrodqsdp -= dtdzmo * rg * t.zldcp * t.zfac3;
     a_dqsdtemp -= dtdzmo * t.dtdzmo * t.zldcp * t.zfac3;
     a_fwat += zldcp * (t.zlvdcp - t.zlsdcp);
     a_lvdcp += zldcp * t.zfwat;
@@ -1263,7 +1326,7 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
     zrho -= zrodqsdp * x.qs * t.zfac2;
     a_qs -= zrodqsdp * t.zrho * t.zfac2;
     a_pap += zrodqsdp * t.zrho * x.qs * (t.zfac2 * t.zfac2);
-    a_foeew -= zrodqsdp * t.zrho * x.qs * c->retv * (t.zfac2 * t.zfac2);
+    a_foeew -= zrodqsdp * t.zrho * x.qs * retv * (t.zfac2 * t.zfac2);
     a_pap += zrho * t.zfac1;
     a_tp1 -= zrho * x.pap * t.rtp2 * t.zfac1;
   }
@@ -1277,9 +1340,9 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
       a_lu_k1 -= ((1.0 - t.zclc) * t.zlude * (t.rlu * t.rlu)) * t.zexpl * a_clc;
       a_clc = a_clc * (1.0 - (1.0 - t.zexpl));
     }
-    a_lude_in += c->ptsphy * t.zgdp * zlude;
-    a_gdp += c->ptsphy * x.lude * zlude;
-    real_t g = c->rg * a_gdp * (t.rdp * t.rdp);
+    a_lude_in += ptsphy * t.zgdp * zlude;
+    a_gdp += ptsphy * x.lude * zlude;
+    real_t g = rg * a_gdp * (t.rdp * t.rdp);
     a_paph_k1 -= g;
     a_paph_k += g;
   }
@@ -1297,7 +1360,7 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
       real_t zqpd = k.zscalm * a_qc * (t.zclc * t.zclc);
       real_t zqcd = (1.0 - k.zscalm) * a_qc * (t.zclc * t.zclc);
       a_clc += (k.zscalm * t.zqpd + (1.0 - k.zscalm) * t.zqcd) * 2.0 * t.zclc * a_qc;
-      if (c->lregcl) a_clc = regcl_factor(t.zqpd, t.zqcd, k.zscalm) * a_clc;
+      if (lregcl) a_clc = regcl_factor(t.zqpd, t.zqcd, k.zscalm) * a_clc;
       const real_t h = 0.5 * t.rzsqrt, rden2 = t.rden * t.rden;
       zqpd -= h * a_clc * t.rden;
       zqcd += h * (t.zqpd * a_clc) * rden2;
@@ -1321,31 +1384,33 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
     if (t.below_rtice) a_tp1 -= zsupsat * 3.e-03;
     if (t.qlim_is_qs) a_qs += a_qlim; else a_qp1 += a_qlim;
 
-    a_dqsdtemp += c->zcons3 * a_corqs;
+    a_dqsdtemp += zcons3 * a_corqs;
     a_qs += t.zfac * t.zcor * a_dqsdtemp;
     real_t zcor = t.zfac * x.qs * a_dqsdtemp;
     real_t zfac = t.zcor * x.qs * a_dqsdtemp;
-    real_t zesdp = c->retv * zcor * (t.zcor * t.zcor);
+    real_t zesdp = retv * zcor * (t.zcor * t.zcor);
     real_t zfacw = t.zfwat * zfac;
     a_fwat += t.zfacw * zfac;
     real_t zfaci = (1.0 - t.zfwat) * zfac;
     a_fwat -= t.zfaci * zfac;
-    a_tp1 -= 2.0 * c->r5ies * zfaci * (t.ri * t.ri * t.ri);
-    a_tp1 -= 2.0 * c->r5les * zfacw * (t.rl * t.rl * t.rl);
+    a_tp1 -= 2.0 * r5ies * zfaci * (t.ri * t.ri * t.ri);
+    a_tp1 -= 2.0 * r5les * zfacw * (t.rl * t.rl * t.rl);
     if (t.esdp_clip) zesdp = 0.0;
     a_foeew += zesdp * t.zqp;
     a_pap -= zesdp * t.zfoeew * (t.zqp * t.zqp);
     real_t z3es, z4es, r4;
-    if (t.cold) { z3es = c->r3ies; z4es = c->r4ies; r4 = t.ri; }
-    else        { z3es = c->r3les; z4es = c->r4les; r4 = t.rl; }
-    a_tp1 += z3es * (c->rtt - z4es) * a_foeew * t.zfoeew * (r4 * r4);
+    if (t.cold) { z3es = r3ies; z4es = r4ies; r4 = t.ri; }
+    else        { z3es = r3les; z4es = r4les; r4 = t.rl; }
+    a_tp1 += z3es * (rtt - z4es) * a_foeew * t.zfoeew * (r4 * r4);
     if (t.cold) a_tp1 += 0.545 * 0.17 * a_fwat * t.zcosh2r;
   }
 
   // thermodynamic constants and first guess (cloudsc2ad.F90:1701-1738)
   {
-    real_t zzz = c->rlvtt * a_lvdcp + c->rlstt * a_lsdcp + c->rlmlt * a_lfdcp;
-    if (!c->rvtmp2_zero) a_qp1 -= zzz * c->rcpd * c->rvtmp2 * (t.zzz * t.zzz);
+    if (!rvtmp2_zero) {
+      real_t zzz = c->rlvtt * a_lvdcp + c->rlstt * a_lsdcp + c->rlmlt * a_lfdcp;
+      a_qp1 -= zzz * c->rcpd * c->rvtmp2 * (t.zzz * t.zzz);
+    }
     a_paph_k1 += a_dp;
     a_paph_k -= a_dp;
   }
@@ -1363,11 +1428,11 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
   ax.lu_k1 = a_lu_k1;
   ax.mfu = a_mfu;
   ax.mfd = a_mfd;
-  ax.gt = c->ptsphy * a_tp1;
-  ax.gq = c->ptsphy * a_qp1;
-  ax.gl = c->ptsphy * a_l;
-  ax.gi = c->ptsphy * a_i;
-  ax.supsat = c->ptsphy * a_qp1;  // the reference ASSIGNS PTSPHY*zqp1 (cloudsc2ad.F90:1733)
+  ax.gt = ptsphy * a_tp1;
+  ax.gq = ptsphy * a_qp1;
+  ax.gl = ptsphy * a_l;
+  ax.gi = ptsphy * a_i;
+  ax.supsat = ptsphy * a_qp1;  // the reference ASSIGNS PTSPHY*zqp1 (cloudsc2ad.F90:1733)
 
   acy.rfl = a_rfl;
   acy.sfl = a_sfl;
