@@ -48,13 +48,15 @@ struct InPtrsRW {
 struct NlArgs {
   Consts c; Geom g; Strides s; InPtrs in; OutPtrs out; const LevelTab* tab;
   double* zero_plane; long long zero_stride; real_t lam;
+  double* ckpt;  // CKPT kernels only: (NPROMA,NLEV,NBLOCKS) plane receiving the precipitation cover carried INTO each level
 };
 struct TlArgs {
   Consts c; Geom g; Strides s, sp; InPtrs in; OutPtrs out; InPtrs din; OutPtrs dout; const LevelTab* tab;
 };
+// The adjoint's trajectory pass IS the NL sweep (with carry checkpoints, nl.ckpt = the scratch plane), so its
+// argument block embeds the NL one.
 struct AdArgs {
-  Consts c; Geom g; Strides s, sa; InPtrs in; OutPtrs out; InPtrsRW ain; OutPtrs aout; const LevelTab* tab;
-  double* scratch;
+  NlArgs nl; Strides sa; InPtrsRW ain; OutPtrs aout;
 };
 typedef const C2_CONST_AS NlArgs* NlArgsP;
 typedef const C2_CONST_AS TlArgs* TlArgsP;
@@ -133,6 +135,11 @@ C2_HD void make_level_in(const RawLevel& cur, real_t paph_k, real_t paph_surf, L
 }
 
 // Tropopause pre-scan (cloudsc2.F90:315-326): the last band level whose first-guess T exceeds the one below.
+// The band is ~40 levels; its 2 x 40 loads are requested in batches of C2_TROP_BATCH levels -- one HBM latency per
+// batch instead of one per level at the start of every wave.
+#ifndef C2_TROP_BATCH
+#define C2_TROP_BATCH 16
+#endif
 template <bool PERT>
 C2_HD real_t tropopause(ConstsP c, LevelTabP tab, InPtrsP p, const LaneOff& o, GeomP g, real_t lam) {
   real_t ztrpaus = 0.1;
@@ -145,14 +152,27 @@ C2_HD real_t tropopause(ConstsP c, LevelTabP tab, InPtrsP p, const LaneOff& o, G
     real_t t0 = pt[o.full + d], g0 = pg[o.cml + d];
     if (PERT) { t0 = pert(t0, lam); g0 = pert(g0, lam); }
     real_t tup = t0 + ptsphy * g0;
-    for (int jk = kb0; jk < kb1; ++jk) {
-      long long d1 = (long long)(jk + 1) * nproma;
-      real_t t1 = pt[o.full + d1], g1 = pg[o.cml + d1];
-      if (PERT) { t1 = pert(t1, lam); g1 = pert(g1, lam); }
-      real_t tdn = t1 + ptsphy * g1;
-      real_t ce = tab->lev[jk].ceta;
-      if (ce > 0.1 && ce < 0.4 && tup > tdn) ztrpaus = ce;
-      tup = tdn;
+    for (int jb = kb0; jb < kb1; jb += C2_TROP_BATCH) {
+      real_t tb[C2_TROP_BATCH], gb[C2_TROP_BATCH];
+#pragma unroll
+      for (int u = 0; u < C2_TROP_BATCH; ++u) {
+        const int jk1 = (jb + u + 1 < kb1) ? jb + u + 1 : kb1;  // clamped: level kb1 <= nlev-1 always exists
+        const long long d1 = (long long)jk1 * nproma;
+        tb[u] = pt[o.full + d1];
+        gb[u] = pg[o.cml + d1];
+      }
+#pragma unroll
+      for (int u = 0; u < C2_TROP_BATCH; ++u) {
+        const int jk = jb + u;
+        if (jk < kb1) {
+          real_t t1 = tb[u], g1 = gb[u];
+          if (PERT) { t1 = pert(t1, lam); g1 = pert(g1, lam); }
+          const real_t tdn = t1 + ptsphy * g1;
+          const real_t ce = tab->lev[jk].ceta;
+          if (ce > 0.1 && ce < 0.4 && tup > tdn) ztrpaus = ce;
+          tup = tdn;
+        }
+      }
     }
   }
   return ztrpaus;
@@ -192,6 +212,16 @@ C2_HD void level_cst(LevelTabP tab, int jk, bool last, LevelCst& k) {
   C2_PIN2(k.ceta, k.zscalm);
 }
 
+// Compile-time variant flags of the column sweeps (template argument F of the functions below and of the kernels)
+enum : unsigned {
+  C2F_QSAT = 1u,     // PQSAT is an input (otherwise SATUR is evaluated in the sweep)
+  C2F_PRECISE = 2u,  // IEEE divisions / libm transcendentals in reference operation order
+  C2F_EVAP = 4u,     // LEVAPLS2 .OR. LDRAIN1D
+  C2F_PERT = 8u,     // NL only: inputs perturbed by lambda*0.01*x (Taylor test)
+  C2F_CKPT = 16u,    // NL only: trajectory pass of the adjoint (carry checkpoints)
+  C2F_TRAJ = 8u,     // TL only: trajectory outputs are stored
+};
+
 // ---------------------------------------------------------------------------------------------------------
 // SATUR for one column
 // ---------------------------------------------------------------------------------------------------------
@@ -211,15 +241,19 @@ C2_HD void satur_column(long long gcol, SaturArgsP a) {
   double* qsat = a->qsat;
   for (int jk = 0; jk < nlev; ++jk) {
     long long d = (long long)jk * nproma;
-    qsat[o.full + d] = satur_point<P>(&a->c, pap[o.full + d], t[o.full + d]);
+    qsat[o.full + d] = satur_point<P>(C2_CONSTS(a), pap[o.full + d], t[o.full + d]);
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // NL: SATUR (optionally fused) + CLOUDSC2 for one column
 // ---------------------------------------------------------------------------------------------------------
-template <bool HAS_QSAT, bool PERT, bool P>
+// CKPT: the sweep is the trajectory pass of the adjoint -- it additionally checkpoints the one carry that is not an
+// output (ZCOVPTOT5(JK-1)); rain and snow flux carries are the outputs PFPLSL5/PFPLSN5 themselves.
+template <unsigned F>
 C2_HD void nl_column(long long gcol, NlArgsP a) {
+  constexpr bool HAS_QSAT = (F & C2F_QSAT) != 0, PERT = (F & C2F_PERT) != 0, P = (F & C2F_PRECISE) != 0, CKPT = (F & C2F_CKPT) != 0, EVAP = (F & C2F_EVAP) != 0;
+  static_assert(!(PERT && CKPT), "the adjoint's trajectory pass is never perturbed");
   LaneOff o; bool active;
   if (!lane_setup(&a->g, &a->s, gcol, o, active)) return;
   const int nlev = a->g.nlev, nproma = a->g.nproma;
@@ -242,16 +276,18 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
     return;
   }
   LevelTabP tab = (LevelTabP)a->tab;
-  ConstsP c = &a->c;
+  ConstsP c = C2_CONSTS(a);
   InPtrsP in = &a->in;
   OutPtrsP out = &a->out;
+  double* ckpt = CKPT ? a->ckpt : nullptr;
+  const long long osc = CKPT ? (gcol / nproma) * ((long long)nproma * nlev) + (gcol % nproma) : 0;
 
   real_t ztrpaus = tropopause<PERT>(c, tab, in, o, &a->g, lam);
   RhCrit rh;
   rhcrit_setup(ztrpaus, rh);
 
   real_t paph_surf = 0.0;
-  if (c->evap) {
+  if (EVAP) {
     paph_surf = in->paph[o.half + (long long)nlev * nproma];
     if (PERT) paph_surf = pert(paph_surf, lam);
   }
@@ -281,9 +317,10 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
     level_cst(tab, jk, last, k);
     LevelIn x;
     make_level_in(cur, paph_k, paph_surf, x);
+    if (CKPT) ckpt[osc + (long long)jk * nproma] = cy.covptot;  // ZCOVPTOT5(JK-1)
     LevelTraj tr;
     LevelOut lo;
-    level_forward<P>(c, k, rh, x, cy, tr, lo);
+    level_forward<P, EVAP>(c, k, rh, x, cy, tr, lo);
     C2_LAUNDER(ap);
     out = &ap->out;
     store_out(out, o, nproma, jk, lo);
@@ -296,15 +333,19 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
 // ---------------------------------------------------------------------------------------------------------
 // TL: SATUR (optionally fused) + CLOUDSC2TL for one column
 // ---------------------------------------------------------------------------------------------------------
-template <bool HAS_QSAT, bool P, bool STORE_TRAJ>
+#ifndef C2_TL_PREFETCH
+#define C2_TL_PREFETCH 1
+#endif
+template <unsigned F>
 C2_HD void tl_column(long long gcol, TlArgsP a) {
+  constexpr bool HAS_QSAT = (F & C2F_QSAT) != 0, P = (F & C2F_PRECISE) != 0, STORE_TRAJ = (F & C2F_TRAJ) != 0, EVAP = (F & C2F_EVAP) != 0;
   LaneOff o, op; bool active;
   if (!lane_setup(&a->g, &a->s, gcol, o, active)) return;
   lane_setup(&a->g, &a->sp, gcol, op, active);
   if (!active) return;
   const int nlev = a->g.nlev, nproma = a->g.nproma;
   LevelTabP tab = (LevelTabP)a->tab;
-  ConstsP c = &a->c;
+  ConstsP c = C2_CONSTS(a);
   InPtrsP in = &a->in, din = &a->din;
   OutPtrsP out = &a->out, dout = &a->dout;
 
@@ -313,7 +354,7 @@ C2_HD void tl_column(long long gcol, TlArgsP a) {
   rhcrit_setup(ztrpaus, rh);
 
   real_t paph_surf = 0.0, dpaph_surf = 0.0;
-  if (c->evap) {
+  if (EVAP) {
     paph_surf = in->paph[o.half + (long long)nlev * nproma];
     dpaph_surf = din->paph[op.half + (long long)nlev * nproma];
   }
@@ -333,11 +374,18 @@ C2_HD void tl_column(long long gcol, TlArgsP a) {
     TlArgsP ap = a;
     C2_LAUNDER(ap);
     in = &ap->in; din = &ap->din;
+#if C2_TL_PREFETCH
     nxt = cur; dnxt = dcur;
     if (!last) {
       load_level<HAS_QSAT>(in, o, nproma, nlev, jk + 1, nxt);
       load_level<true>(din, op, nproma, nlev, jk + 1, dnxt);
     }
+#else
+    if (jk > 0) {
+      load_level<HAS_QSAT>(in, o, nproma, nlev, jk, cur);
+      load_level<true>(din, op, nproma, nlev, jk, dcur);
+    }
+#endif
     if (!HAS_QSAT) cur.qsat = satur_point<P>(c, cur.pap, cur.t);
 
     LevelCst k;
@@ -347,146 +395,168 @@ C2_HD void tl_column(long long gcol, TlArgsP a) {
     make_level_in(dcur, dpaph_k, dpaph_surf, dx);
     LevelTraj tr;
     LevelOut lo, dlo;
-    level_forward<P>(c, k, rh, x, cy, tr, lo);
+    level_forward<P, EVAP>(c, k, rh, x, cy, tr, lo);
     level_tl(c, k, x, tr, dx, dcy, dlo);
     C2_LAUNDER(ap);
     out = &ap->out; dout = &ap->dout;
     if (STORE_TRAJ) store_out(out, o, nproma, jk, lo);
     store_out(dout, op, nproma, jk, dlo);
     paph_k = cur.paph_k1; dpaph_k = dcur.paph_k1;
+#if C2_TL_PREFETCH
     cur = nxt;
     dcur = dnxt;
+#endif
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// AD for one column: forward trajectory sweep (checkpointing the three carries: rain and snow flux live in the
-// trajectory outputs PFPLSL5/PFPLSN5 that have to be written anyway, the precipitation cover goes to `scratch`),
-// then the reverse sweep re-evaluates each level's trajectory and applies the transposed level.
+// AD for one column.  Two passes: the trajectory pass is nl_column<.., CKPT=true> -- it writes the trajectory
+// outputs and checkpoints the three carries (rain and snow flux live in the outputs PFPLSL5/PFPLSN5 that have to be
+// written anyway, the precipitation cover goes to the scratch plane).  The reverse pass below re-evaluates each
+// level's trajectory from its checkpoint and applies the transposed level.
 // ---------------------------------------------------------------------------------------------------------
-template <bool HAS_QSAT, bool P>
-C2_HD void ad_column(long long gcol, AdArgsP a) {
+#ifndef C2_AD_PREFETCH
+#define C2_AD_PREFETCH 0
+#endif
+
+// Everything the reverse pass reads for level jk: trajectory inputs, the three checkpointed carries, the output
+// adjoints, and the OLD values of the input adjoints that are accumulated into.  (Written as `a[i] += x` after the
+// compute, each read-modify-write would wait for its own HBM round trip: the compiler cannot move a load above a
+// store that might alias.)
+struct AdLevelLoads {
+  RawLevel cur;   // trajectory inputs; paph_k1 is NOT loaded (it is the paph_k of the level below, already in a register)
+  real_t paph_k;
+  Carry cy;
+  LevelOut ya;
+  RawLevel xo;    // old input adjoints (PSUPSAT is assigned, not accumulated: not read)
+};
+
+template <bool HAS_QSAT>
+C2_HD void ad_load_level(AdArgsP ap, const LaneOff& o, const LaneOff& oa, long long osc, int nproma, int nlev, int jk,
+                         AdLevelLoads& L) {
+  const bool last = (jk == nlev - 1);
+  const long long d = (long long)jk * nproma;
+  const long long d1 = d + nproma;
+  {
+    const InPtrs p = ap->nl.in;
+    L.paph_k = p.paph[o.half + d];
+    L.cur.lu_k1 = last ? 0.0 : p.lu[o.full + d1];
+    L.cur.pap = p.pap[o.full + d];
+    L.cur.q = p.q[o.full + d];
+    L.cur.t = p.t[o.full + d];
+    L.cur.l = p.l[o.clv + d];
+    L.cur.i = p.i[o.clv + d];
+    L.cur.lude = p.lude[o.full + d];
+    L.cur.mfu = p.mfu[o.full + d];
+    L.cur.mfd = p.mfd[o.full + d];
+    L.cur.gt = p.gt[o.cml + d];
+    L.cur.gq = p.gq[o.cml + d];
+    L.cur.gl = p.gl[o.cml + d];
+    L.cur.gi = p.gi[o.cml + d];
+    L.cur.supsat = p.supsat[o.full + d];
+    if (HAS_QSAT) L.cur.qsat = p.qsat[o.full + d];
+  }
+  {
+    const OutPtrs po = ap->nl.out;
+    L.cy.rfl = po.fplsl[o.half + d];  // ZRFL5(JK) = PFPLSL5(JK)
+    L.cy.sfl = po.fplsn[o.half + d];
+  }
+  L.cy.covptot = ap->nl.ckpt[osc + d];
+  const OutPtrs pa = ap->aout;
+  L.ya.tent = pa.tent[oa.loc + d];
+  L.ya.tenq = pa.tenq[oa.loc + d];
+  L.ya.tenl = pa.tenl[oa.loc + d];
+  L.ya.teni = pa.teni[oa.loc + d];
+  L.ya.clc = pa.clc[oa.full + d];
+  L.ya.covptot = pa.covptot[oa.full + d];
+  L.ya.fplsn = pa.fplsn[oa.half + d1];
+  L.ya.fplsl = pa.fplsl[oa.half + d1];
+  L.ya.fhpsn = pa.fhpsn[oa.half + d1];
+  L.ya.fhpsl = pa.fhpsl[oa.half + d1];
+  const InPtrsRW px = ap->ain;
+  L.xo.pap = px.pap[oa.full + d];
+  L.xo.q = px.q[oa.full + d];
+  L.xo.qsat = px.qsat[oa.full + d];
+  L.xo.t = px.t[oa.full + d];
+  L.xo.l = px.l[oa.clv + d];
+  L.xo.i = px.i[oa.clv + d];
+  L.xo.lude = px.lude[oa.full + d];
+  L.xo.mfu = px.mfu[oa.full + d];
+  L.xo.mfd = px.mfd[oa.full + d];
+  L.xo.gt = px.gt[oa.cml + d];
+  L.xo.gq = px.gq[oa.cml + d];
+  L.xo.gl = px.gl[oa.cml + d];
+  L.xo.gi = px.gi[oa.cml + d];
+  L.xo.lu_k1 = last ? 0.0 : px.lu[oa.full + d1];
+  L.xo.paph_k1 = last ? 0.0 : px.paph[oa.half + d1];
+}
+
+// reverse sweep (cloudsc2ad.F90:877-1740); the trajectory pass has run before
+template <unsigned F>
+C2_HD void ad_reverse_column(long long gcol, AdArgsP a) {
+  constexpr bool HAS_QSAT = (F & C2F_QSAT) != 0, P = (F & C2F_PRECISE) != 0, EVAP = (F & C2F_EVAP) != 0;
   LaneOff o, oa; bool active;
-  if (!lane_setup(&a->g, &a->s, gcol, o, active)) return;
-  lane_setup(&a->g, &a->sa, gcol, oa, active);
+  if (!lane_setup(&a->nl.g, &a->nl.s, gcol, o, active)) return;
+  lane_setup(&a->nl.g, &a->sa, gcol, oa, active);
   if (!active) return;
-  const int nlev = a->g.nlev, nproma = a->g.nproma;
-  LevelTabP tab = (LevelTabP)a->tab;
-  ConstsP c = &a->c;
-  InPtrsP in = &a->in;
-  OutPtrsP out = &a->out, aout = &a->aout;
-  InPtrsRWP ain = &a->ain;
-  double* scratch = a->scratch;
+  const int nlev = a->nl.g.nlev, nproma = a->nl.g.nproma;
+  LevelTabP tab = (LevelTabP)a->nl.tab;
+  ConstsP c = C2_CONSTS(&a->nl);
+  InPtrsP in = &a->nl.in;
 
   // scratch: (NPROMA, NLEV, NBLOCKS) contiguous
   const long long osc = (gcol / nproma) * ((long long)nproma * nlev) + (gcol % nproma);
 
-  real_t ztrpaus = tropopause<false>(c, tab, in, o, &a->g, 0.0);
+  real_t ztrpaus = tropopause<false>(c, tab, in, o, &a->nl.g, 0.0);
   RhCrit rh;
   rhcrit_setup(ztrpaus, rh);
-  real_t paph_surf = 0.0;
-  if (c->evap) paph_surf = in->paph[o.half + (long long)nlev * nproma];
+  const real_t paph_bottom = in->paph[o.half + (long long)nlev * nproma];
+  const real_t paph_surf = EVAP ? paph_bottom : 0.0;
 
-  // ---- forward sweep (cloudsc2ad.F90:366-866) ----
-  store_top(out, o, c);
-  {
-    Carry cy; cy.rfl = 0.0; cy.sfl = 0.0; cy.covptot = 0.0;
-    RawLevel cur, nxt;
-    real_t paph_k = in->paph[o.half];
-    load_level<HAS_QSAT>(in, o, nproma, nlev, 0, cur);
-    for (int jk = 0; jk < nlev; ++jk) {
-      const bool last = (jk == nlev - 1);
-      AdArgsP ap = a;
-      C2_LAUNDER(ap);
-      in = &ap->in;
-      nxt = cur;
-      if (!last) load_level<HAS_QSAT>(in, o, nproma, nlev, jk + 1, nxt);
-      if (!HAS_QSAT) cur.qsat = satur_point<P>(c, cur.pap, cur.t);
-      LevelCst k;
-      level_cst(tab, jk, last, k);
-      LevelIn x;
-      make_level_in(cur, paph_k, paph_surf, x);
-      scratch[osc + (long long)jk * nproma] = cy.covptot;  // ZCOVPTOT5(JK-1)
-      LevelTraj tr;
-      LevelOut lo;
-      level_forward<P>(c, k, rh, x, cy, tr, lo);
-      C2_LAUNDER(ap);
-      out = &ap->out;
-      store_out(out, o, nproma, jk, lo);
-      paph_k = cur.paph_k1;
-      cur = nxt;
-    }
-  }
-
-  // ---- reverse sweep (cloudsc2ad.F90:877-1740) ----
   Carry acy; acy.rfl = 0.0; acy.sfl = 0.0; acy.covptot = 0.0;
   real_t paph_pending = 0.0;  // contribution of level jk+1 to the PAPHP1 adjoint at half level jk+1
   real_t surf_acc = 0.0;      // PAPHP1(KLEV+1) adjoint, written once at the end
+  real_t paph_k1 = paph_bottom;
+  AdLevelLoads L;
+#if C2_AD_PREFETCH
+  ad_load_level<HAS_QSAT>(a, o, oa, osc, nproma, nlev, nlev - 1, L);
+#endif
   for (int jk = nlev - 1; jk >= 0; --jk) {
     const bool last = (jk == nlev - 1);
     const long long d = (long long)jk * nproma;
     const long long d1 = d + nproma;
     AdArgsP ap = a;
     C2_LAUNDER(ap);
-    in = &ap->in; out = &ap->out;
-    // ---- all loads of this level are issued up front: trajectory inputs, the three checkpointed carries, the output
-    // adjoints, and the OLD values of the 16 input adjoints that are accumulated into at the end.  (Written as
-    // `a[i] += x` after the compute, each read-modify-write would wait for its own HBM round trip: the compiler
-    // cannot move a load above a store that might alias.) ----
-    RawLevel cur;
-    load_level<HAS_QSAT>(in, o, nproma, nlev, jk, cur);
-    const real_t paph_k = in->paph[o.half + d];
-    Carry cy;
-    {
-      const OutPtrs po = *out;
-      cy.rfl = po.fplsl[o.half + d];  // ZRFL5(JK) = PFPLSL5(JK)
-      cy.sfl = po.fplsn[o.half + d];
-    }
-    cy.covptot = scratch[osc + d];
-    const OutPtrs pa = ap->aout;
-    const InPtrsRW px = ap->ain;
-    LevelOut ya;  // output adjoints of this level; enthalpy-flux adjoints folded in below (cloudsc2ad.F90:914-921)
-    ya.tent = pa.tent[oa.loc + d];
-    ya.tenq = pa.tenq[oa.loc + d];
-    ya.tenl = pa.tenl[oa.loc + d];
-    ya.teni = pa.teni[oa.loc + d];
-    ya.clc = pa.clc[oa.full + d];
-    ya.covptot = pa.covptot[oa.full + d];
-    ya.fplsn = pa.fplsn[oa.half + d1];
-    ya.fplsl = pa.fplsl[oa.half + d1];
-    ya.fhpsn = pa.fhpsn[oa.half + d1];
-    ya.fhpsl = pa.fhpsl[oa.half + d1];
-    RawLevel xo;  // old input adjoints (PSUPSAT is assigned, not accumulated: not read)
-    xo.pap = px.pap[oa.full + d];
-    xo.q = px.q[oa.full + d];
-    xo.qsat = px.qsat[oa.full + d];
-    xo.t = px.t[oa.full + d];
-    xo.l = px.l[oa.clv + d];
-    xo.i = px.i[oa.clv + d];
-    xo.lude = px.lude[oa.full + d];
-    xo.mfu = px.mfu[oa.full + d];
-    xo.mfd = px.mfd[oa.full + d];
-    xo.gt = px.gt[oa.cml + d];
-    xo.gq = px.gq[oa.cml + d];
-    xo.gl = px.gl[oa.cml + d];
-    xo.gi = px.gi[oa.cml + d];
-    xo.lu_k1 = last ? 0.0 : px.lu[oa.full + d1];
-    xo.paph_k1 = last ? 0.0 : px.paph[oa.half + d1];
+#if C2_AD_PREFETCH
+    // level jk-1 is requested before level jk is evaluated; none of level jk's stores touches what it reads
+    // (different level index in every plane), so issuing the loads first is safe and the compiler keeps the order
+    AdLevelLoads N = L;
+    if (jk > 0) ad_load_level<HAS_QSAT>(ap, o, oa, osc, nproma, nlev, jk - 1, N);
+#else
+    ad_load_level<HAS_QSAT>(ap, o, oa, osc, nproma, nlev, jk, L);
+#endif
+    RawLevel& cur = L.cur;
+    cur.paph_k1 = paph_k1;
+    const RawLevel& xo = L.xo;
+    LevelOut ya = L.ya;  // enthalpy-flux adjoints folded in below (cloudsc2ad.F90:914-921)
 
     if (!HAS_QSAT) cur.qsat = satur_point<P>(c, cur.pap, cur.t);
     LevelCst k;
     level_cst(tab, jk, last, k);
     LevelIn x;
-    make_level_in(cur, paph_k, paph_surf, x);
+    make_level_in(cur, L.paph_k, paph_surf, x);
     LevelTraj tr;
     LevelOut lo;
-    level_forward<P>(c, k, rh, x, cy, tr, lo);
+    level_forward<P, EVAP>(c, k, rh, x, L.cy, tr, lo);
 
     ya.fplsn = ya.fplsn - ya.fhpsn * c->rlstt;
     ya.fplsl = ya.fplsl - ya.fhpsl * c->rlvtt;
     LevelIn ax;
     level_ad(c, k, x, tr, ya, acy, ax);
 
+    C2_LAUNDER(ap);
+    const InPtrsRW px = ap->ain;
+    const OutPtrs pa = ap->aout;
     // accumulate input adjoints (cloudsc2ad.F90:1723-1738; PSUPSAT assigned, :1733)
     px.pap[oa.full + d] = xo.pap + ax.pap;
     px.q[oa.full + d] = xo.q + ax.q;
@@ -522,8 +592,14 @@ C2_HD void ad_column(long long gcol, AdArgsP a) {
     pa.fplsn[oa.half + d1] = 0.0;
     pa.fhpsl[oa.half + d1] = 0.0;
     pa.fhpsn[oa.half + d1] = 0.0;
+
+    paph_k1 = L.paph_k;
+#if C2_AD_PREFETCH
+    L = N;
+#endif
   }
-  ain = &a->ain; aout = &a->aout;
+  InPtrsRWP ain = &a->ain;
+  OutPtrsP aout = &a->aout;
   ain->paph[oa.half] += paph_pending;
   ain->paph[oa.half + (long long)nlev * nproma] += surf_acc;
   // the adjoint of the (constant zero) top fluxes is discarded (cloudsc2ad.F90:1678-1679,917-919)

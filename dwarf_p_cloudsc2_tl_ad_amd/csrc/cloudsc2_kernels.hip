@@ -12,7 +12,9 @@
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
+#include <array>
 #include <atomic>
+#include <utility>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -60,42 +62,6 @@ bool device_ok() {
 // ---------------------------------------------------------------------------------------------------------
 // launch-invariant constants and per-level tables
 // ---------------------------------------------------------------------------------------------------------
-Consts make_consts(const cloudsc2_params& p, double ptsphy) {
-  Consts c;
-  c.rg = p.rg; c.rd = p.rd; c.rcpd = p.rcpd; c.retv = p.retv; c.rlvtt = p.rlvtt; c.rlstt = p.rlstt;
-  c.rlmlt = p.rlmlt; c.rtt = p.rtt;
-  c.r2es = p.r2es; c.r3les = p.r3les; c.r3ies = p.r3ies; c.r4les = p.r4les; c.r4ies = p.r4ies;
-  c.r5les = p.r5les; c.r5ies = p.r5ies; c.r5alvcp = p.r5alvcp; c.r5alscp = p.r5alscp;
-  c.ralvdcp = p.ralvdcp; c.ralsdcp = p.ralsdcp;
-  c.rtwat = p.rtwat; c.rtice = p.rtice; c.rtwat_rtice_r = p.rtwat_rtice_r; c.rvtmp2 = p.rvtmp2;
-  c.rlmin = p.rlmin; c.rpecons = p.rpecons; c.rlptrc = p.rlptrc;
-  c.ptsphy = ptsphy;
-  // cloudsc2.F90:235-240, cloudsc2tl.F90:321-328
-  c.zckcodtl = 2.0 * p.rkconv * ptsphy;
-  c.zckcodti = 5.0 * p.rkconv * ptsphy;
-  c.zckcodtla = c.zckcodtl / 100.0;
-  c.zckcodtia = c.zckcodti / 100.0;
-  c.zcons2 = 1.0 / (ptsphy * p.rg);
-  c.zcons3 = p.rlvtt / p.rcpd;
-  c.zmeltp2 = p.rtt + 2.0;
-  c.zqtmst = 1.0 / ptsphy;
-  c.evap = (p.levapls2 || p.ldrain1d) ? 1 : 0;
-  // cloudsc2.F90:505-509,522-526
-  c.zlcrit_l = c.evap ? 1.9 * p.rclcrit : p.rclcrit * 2.0;
-  c.zlcrit_i = c.evap ? 1.e-04 : p.rclcrit * 2.0;
-  c.rcpd_r = 1.0 / p.rcpd;
-  c.zlcrit_l_r = 1.0 / c.zlcrit_l;
-  c.zlcrit_i_r = 1.0 / c.zlcrit_i;
-  c.zcons2_r = ptsphy * p.rg;
-  c.rvtmp2_zero = (p.rvtmp2 == 0.0) ? 1 : 0;
-  c.zzz0 = 1.0 / (p.rcpd + p.rcpd * p.rvtmp2 * 0.0);
-  c.zlfdcp0_r = 1.0 / (p.rlmlt * c.zzz0);
-  c.lregcl = p.lregcl ? 1 : 0;
-  c.nlev = p.nlev;
-  fill_stage_blocks(c);
-  return c;
-}
-
 // Device copies of the level tables are immutable once created and keyed by content, so launches on
 // different streams never race on them.
 struct TabEntry {
@@ -179,20 +145,44 @@ __global__ void __launch_bounds__(kBlock) satur_kernel(SaturArgs args) {
   C2_KERNEL_BODY(satur_column<P>(global_column(), kernarg<SaturArgs>()));
 }
 
-template <bool HAS_QSAT, bool PERT, bool P>
+template <unsigned F>
 __global__ void C2_BOUNDS(C2_NL_WAVES) nl_kernel(NlArgs args) {
-  C2_KERNEL_BODY((nl_column<HAS_QSAT, PERT, P>(global_column(), kernarg<NlArgs>())));
+  C2_KERNEL_BODY((nl_column<F>(global_column(), kernarg<NlArgs>())));
 }
 
-template <bool HAS_QSAT, bool P, bool STORE_TRAJ>
+template <unsigned F>
 __global__ void C2_BOUNDS(C2_TL_WAVES) tl_kernel(TlArgs args) {
-  C2_KERNEL_BODY((tl_column<HAS_QSAT, P, STORE_TRAJ>(global_column(), kernarg<TlArgs>())));
+  C2_KERNEL_BODY((tl_column<F>(global_column(), kernarg<TlArgs>())));
 }
 
-template <bool HAS_QSAT, bool P>
-__global__ void C2_BOUNDS(C2_AD_WAVES) ad_kernel(AdArgs args) {
-  C2_KERNEL_BODY((ad_column<HAS_QSAT, P>(global_column(), kernarg<AdArgs>())));
+// C2_AD_FUSED=1: one kernel runs a column's trajectory pass and then its reverse pass (waves in the bandwidth-heavy
+// forward phase and waves in the arithmetic-heavy reverse phase share the CUs); 0: two kernels in stream order.
+#ifndef C2_AD_FUSED
+#define C2_AD_FUSED 1
+#endif
+template <unsigned F>
+__global__ void C2_BOUNDS(C2_AD_WAVES) ad_reverse_kernel(AdArgs args) {
+  C2_KERNEL_BODY((ad_reverse_column<F>(global_column(), kernarg<AdArgs>())));
 }
+template <unsigned F>
+__global__ void C2_BOUNDS(C2_AD_WAVES) ad_kernel(AdArgs args) {
+  C2_KERNEL_BODY((nl_column<F | C2F_CKPT>(global_column(), &kernarg<AdArgs>()->nl)));
+  C2_KERNEL_BODY((ad_reverse_column<F>(global_column(), kernarg<AdArgs>())));
+}
+
+// Variant tables: kernel<F> for every valid flag combination F, indexed by F (see C2F_* in cloudsc2_column.hpp).
+template <class Args> using KernelFn = void (*)(Args);
+#define C2_VARIANT_TABLE(table, kern, Args, NF, valid_expr)                                                        \
+  template <unsigned F> constexpr KernelFn<Args> table##_entry() {                                                 \
+    if constexpr (valid_expr) return kern<F>; else return nullptr;                                                 \
+  }                                                                                                                \
+  template <unsigned... F> constexpr std::array<KernelFn<Args>, sizeof...(F)> table##_make(                        \
+      std::integer_sequence<unsigned, F...>) { return {{table##_entry<F>()...}}; }                                 \
+  [[maybe_unused]] const std::array<KernelFn<Args>, NF> table = table##_make(std::make_integer_sequence<unsigned, NF>{});
+C2_VARIANT_TABLE(g_nl_kernels, nl_kernel, NlArgs, 32, !((F & C2F_PERT) && (F & C2F_CKPT)) && (C2_AD_FUSED ? !(F & C2F_CKPT) : true))
+C2_VARIANT_TABLE(g_tl_kernels, tl_kernel, TlArgs, 16, true)
+C2_VARIANT_TABLE(g_ad_reverse_kernels, ad_reverse_kernel, AdArgs, 8, !C2_AD_FUSED)
+C2_VARIANT_TABLE(g_ad_kernels, ad_kernel, AdArgs, 8, C2_AD_FUSED != 0)
 
 // ---------------------------------------------------------------------------------------------------------
 // Test-norm kernels
@@ -364,6 +354,16 @@ int check_geom(const cloudsc2_params* prm, int nproma, int nlev, int ngptot, Geo
 
 inline unsigned grid_for(long long ncols, int block) { return (unsigned)((ncols + block - 1) / block); }
 
+template <class Args>
+int launch_variant(KernelFn<Args> fn, const Args& args, long long ncols, hipStream_t st) {
+  if (!fn) return fail(CLOUDSC2_EINVAL, "kernel variant not built");
+  Args a = args;
+  void* argv[] = {&a};
+  HIP_TRY(hipLaunchKernel((const void*)fn, dim3(grid_for(ncols, kBlock)), dim3(kBlock), argv, 0, st));
+  return 0;
+}
+
+
 }  // namespace
 
 // =========================================================================================================
@@ -455,23 +455,13 @@ int cloudsc2_nl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
   args.c = make_consts(*prm, ptsphy);
   args.g = g; args.s = s; args.in = ip; args.out = op; args.tab = tab;
   args.zero_plane = zero_plane.ptr; args.zero_stride = zero_plane.block_stride; args.lam = pert_lambda;
-  dim3 grid(grid_for(g.ncols_pad, kBlock)), block(kBlock);
-  hipStream_t st = (hipStream_t)stream;
-  const bool has_qsat = in->qsat.ptr != nullptr;
-  const bool pertb = pert_lambda != 0.0;
-  const bool precise = g_precise.load() != 0;
-#define C2_NL(HQ, PT)                                                                \
-  do {                                                                               \
-    if (precise) hipLaunchKernelGGL((nl_kernel<HQ, PT, true>), grid, block, 0, st, args);  \
-    else hipLaunchKernelGGL((nl_kernel<HQ, PT, false>), grid, block, 0, st, args);   \
-  } while (0)
-  if (has_qsat && pertb) C2_NL(true, true);
-  else if (has_qsat) C2_NL(true, false);
-  else if (pertb) C2_NL(false, true);
-  else C2_NL(false, false);
-#undef C2_NL
-  HIP_TRY(hipGetLastError());
-  return 0;
+  args.ckpt = nullptr;
+  unsigned f = 0;
+  if (in->qsat.ptr) f |= C2F_QSAT;
+  if (pert_lambda != 0.0) f |= C2F_PERT;
+  if (g_precise.load()) f |= C2F_PRECISE;
+  if (args.c.evap) f |= C2F_EVAP;
+  return launch_variant(g_nl_kernels[f], args, g.ncols_pad, (hipStream_t)stream);
 }
 
 int cloudsc2_tl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
@@ -498,21 +488,12 @@ int cloudsc2_tl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
   TlArgs args;
   args.c = make_consts(*prm, ptsphy);
   args.g = g; args.s = s; args.sp = sp; args.in = ip; args.out = op; args.din = dip; args.dout = dop; args.tab = tab;
-  dim3 grid(grid_for(g.ncols_pad, kBlock)), block(kBlock);
-  hipStream_t st = (hipStream_t)stream;
-  const bool precise = g_precise.load() != 0;
-  const bool hq = traj_in->qsat.ptr != nullptr;
-#define C2_TL(HQ, PR, ST) hipLaunchKernelGGL((tl_kernel<HQ, PR, ST>), grid, block, 0, st, args)
-  if (store_traj) {
-    if (hq) { if (precise) C2_TL(true, true, true); else C2_TL(true, false, true); }
-    else    { if (precise) C2_TL(false, true, true); else C2_TL(false, false, true); }
-  } else {
-    if (hq) { if (precise) C2_TL(true, true, false); else C2_TL(true, false, false); }
-    else    { if (precise) C2_TL(false, true, false); else C2_TL(false, false, false); }
-  }
-#undef C2_TL
-  HIP_TRY(hipGetLastError());
-  return 0;
+  unsigned f = 0;
+  if (traj_in->qsat.ptr) f |= C2F_QSAT;
+  if (store_traj) f |= C2F_TRAJ;
+  if (g_precise.load()) f |= C2F_PRECISE;
+  if (args.c.evap) f |= C2F_EVAP;
+  return launch_variant(g_tl_kernels[f], args, g.ncols_pad, (hipStream_t)stream);
 }
 
 int cloudsc2_ad_launch(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
@@ -537,21 +518,21 @@ int cloudsc2_ad_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
   const LevelTab* tab;
   if ((rc = get_tables(*prm, &tab, &g.kb0, &g.kb1))) return rc;
   AdArgs args;
-  args.c = make_consts(*prm, ptsphy);
-  args.g = g; args.s = s; args.sa = sa; args.in = ip; args.out = op; args.ain = aip; args.aout = aop; args.tab = tab;
-  args.scratch = scratch;
-  dim3 grid(grid_for(g.ncols_pad, kBlock)), block(kBlock);
-  hipStream_t st = (hipStream_t)stream;
-  const bool precise = g_precise.load() != 0;
-  if (traj_in->qsat.ptr) {
-    if (precise) hipLaunchKernelGGL((ad_kernel<true, true>), grid, block, 0, st, args);
-    else hipLaunchKernelGGL((ad_kernel<true, false>), grid, block, 0, st, args);
-  } else {
-    if (precise) hipLaunchKernelGGL((ad_kernel<false, true>), grid, block, 0, st, args);
-    else hipLaunchKernelGGL((ad_kernel<false, false>), grid, block, 0, st, args);
-  }
-  HIP_TRY(hipGetLastError());
-  return 0;
+  args.nl.c = make_consts(*prm, ptsphy);
+  args.nl.g = g; args.nl.s = s; args.nl.in = ip; args.nl.out = op; args.nl.tab = tab;
+  args.nl.zero_plane = nullptr; args.nl.zero_stride = 0; args.nl.lam = 0.0; args.nl.ckpt = scratch;
+  args.sa = sa; args.ain = aip; args.aout = aop;
+  unsigned f = 0;
+  if (traj_in->qsat.ptr) f |= C2F_QSAT;
+  if (g_precise.load()) f |= C2F_PRECISE;
+  if (args.nl.c.evap) f |= C2F_EVAP;
+#if C2_AD_FUSED
+  return launch_variant(g_ad_kernels[f], args, g.ncols_pad, (hipStream_t)stream);
+#else
+  // trajectory pass (NL kernel + carry checkpoints), then the reverse pass, in stream order
+  if ((rc = launch_variant(g_nl_kernels[f | C2F_CKPT], args.nl, g.ncols_pad, (hipStream_t)stream))) return rc;
+  return launch_variant(g_ad_reverse_kernels[f], args, g.ncols_pad, (hipStream_t)stream);
+#endif
 }
 
 static int ten_ptrs(const cloudsc2_outputs* o, int nlev, TenPtrs& t) {

@@ -20,6 +20,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include "../../include/cloudsc2_hip.h"
 
 namespace cloudsc2 {
 
@@ -43,24 +44,23 @@ typedef double real_t;
 // ---------------------------------------------------------------------------------------------------------
 // fp64 math building blocks.  The level costs ~50 divisions, ~12 exp and a tanh in the reference formulation
 // (SURVEY.md 8d); on CDNA4 an IEEE fp64 division is ~13 instructions around a quarter-rate v_rcp_f64, so the
-// arithmetic, not HBM, bounds the kernel.  Hence: reciprocals are taken with v_rcp_f64 + two Newton steps and
+// arithmetic, not HBM, bounds the kernel.  Hence: reciprocals are taken with v_rcp_f64 + one third-order step and
 // shared / batch-inverted (Montgomery) between quotients, exp is a branch-free Cody-Waite + degree-13 kernel,
 // tanh comes from one exp.  Results differ from correctly rounded ones by a few ulp (parity tolerance: 1e-10).
 // ---------------------------------------------------------------------------------------------------------
 C2_HD real_t c2_rcp(real_t x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  real_t r = __builtin_amdgcn_rcp(x);       // ~2^-23 relative
+  // v_rcp_f64 is good to ~2^-23; one third-order step r(1 + e + e^2), e = 1 - x r, takes that to 2^-69 < 1/2 ulp
+  // in three fma (two Newton steps need four)
+  real_t r = __builtin_amdgcn_rcp(x);
   real_t e = __builtin_fma(-x, r, 1.0);
-  r = __builtin_fma(r, e, r);               // ~2^-46
-  e = __builtin_fma(-x, r, 1.0);
-  r = __builtin_fma(r, e, r);               // ~2^-52
-  return r;
+  real_t t = __builtin_fma(e, e, e);
+  return __builtin_fma(r, t, r);
 #else
   return 1.0 / x;
 #endif
 }
 
-// 1/a and 1/b from one reciprocal
 C2_HD void c2_rcp2(real_t a, real_t b, real_t& ra, real_t& rb) {
   real_t r = c2_rcp(a * b);
   ra = b * r;
@@ -84,28 +84,28 @@ C2_HD real_t quot(real_t num, real_t den, real_t rden) { return PRECISE ? num / 
 template <bool PRECISE>
 C2_HD real_t recip(real_t den) { return PRECISE ? 1.0 / den : c2_rcp(den); }
 
+// exp: n = round(x log2 e) by the 1.5*2^52 trick (the low dword of the biased sum IS the integer n, no convert),
+// r = x - n ln2 in one fma (ln2 rounded once: the error n*7.6e-17 stays below 3e-15 for |x| < 60, 2.4e-14 at the
+// underflow end), degree-10 near-minimax polynomial on |r| <= ln2/2 (3.3e-16), one v_ldexp_f64: 15 instructions.
 C2_HD real_t c2_exp(real_t x) {
-  const real_t log2e = 1.44269504088896338700e+00;
-  const real_t ln2hi = 6.93147180369123816490e-01, ln2lo = 1.90821492927058770002e-10;
-  x = fmin(fmax(x, -746.0), 710.0);
-  real_t n = rint(x * log2e);
-  real_t r = fma(-n, ln2hi, x);
-  r = fma(-n, ln2lo, r);
-  real_t p = 1.6059043836821613e-10;          // 1/13!
-  p = fma(p, r, 2.08767569878681e-09);        // 1/12!
-  p = fma(p, r, 2.505210838544172e-08);       // 1/11!
-  p = fma(p, r, 2.755731922398589e-07);       // 1/10!
-  p = fma(p, r, 2.7557319223985893e-06);      // 1/9!
-  p = fma(p, r, 2.48015873015873e-05);        // 1/8!
-  p = fma(p, r, 1.984126984126984e-04);       // 1/7!
-  p = fma(p, r, 1.3888888888888889e-03);      // 1/6!
-  p = fma(p, r, 8.333333333333333e-03);       // 1/5!
-  p = fma(p, r, 4.1666666666666664e-02);      // 1/4!
-  p = fma(p, r, 1.6666666666666666e-01);      // 1/3!
-  p = fma(p, r, 0.5);
+  const real_t log2e = 1.44269504088896338700e+00, ln2 = 6.93147180559945286227e-01;
+  const real_t magic = 6755399441055744.0;  // 1.5 * 2^52
+  x = fmax(x, -1000.0);                     // keeps n inside 32 bits; exp(-1000) underflows to 0 like exp(-inf)
+  const real_t nb = fma(x, log2e, magic);
+  const real_t n = nb - magic;
+  const real_t r = fma(-n, ln2, x);
+  real_t p = 0x1.28a2c6cc1d7acp-22;
+  p = fma(p, r, 0x1.72faf086f80f0p-19);
+  p = fma(p, r, 0x1.a019a6617b7afp-16);
+  p = fma(p, r, 0x1.a01978c64c250p-13);
+  p = fma(p, r, 0x1.6c16c17f4783ep-10);
+  p = fma(p, r, 0x1.1111112dd6a6dp-7);
+  p = fma(p, r, 0x1.55555555520a2p-5);
+  p = fma(p, r, 0x1.555555554b755p-3);
+  p = fma(p, r, 0x1.0000000000005p-1);
+  p = fma(p, r, 0x1.000000000001ep+0);
   p = fma(p, r, 1.0);
-  p = fma(p, r, 1.0);
-  return ldexp(p, (int)n);
+  return ldexp(p, (int)(unsigned)__builtin_bit_cast(unsigned long long, nb));
 }
 
 struct StageBlock { real_t v[8]; };
@@ -189,6 +189,43 @@ inline void fill_stage_blocks(Consts& c) {
   k[KF_SPARE0] = k[KF_SPARE1] = k[KF_SPARE2] = k[KF_SPARE3] = k[KF_SPARE4] = 0.0;
 }
 
+// host side: everything the kernels need besides fields and level tables, from the caller's parameter block
+inline Consts make_consts(const cloudsc2_params& p, double ptsphy) {
+  Consts c;
+  c.rg = p.rg; c.rd = p.rd; c.rcpd = p.rcpd; c.retv = p.retv; c.rlvtt = p.rlvtt; c.rlstt = p.rlstt;
+  c.rlmlt = p.rlmlt; c.rtt = p.rtt;
+  c.r2es = p.r2es; c.r3les = p.r3les; c.r3ies = p.r3ies; c.r4les = p.r4les; c.r4ies = p.r4ies;
+  c.r5les = p.r5les; c.r5ies = p.r5ies; c.r5alvcp = p.r5alvcp; c.r5alscp = p.r5alscp;
+  c.ralvdcp = p.ralvdcp; c.ralsdcp = p.ralsdcp;
+  c.rtwat = p.rtwat; c.rtice = p.rtice; c.rtwat_rtice_r = p.rtwat_rtice_r; c.rvtmp2 = p.rvtmp2;
+  c.rlmin = p.rlmin; c.rpecons = p.rpecons; c.rlptrc = p.rlptrc;
+  c.ptsphy = ptsphy;
+  // cloudsc2.F90:235-240, cloudsc2tl.F90:321-328
+  c.zckcodtl = 2.0 * p.rkconv * ptsphy;
+  c.zckcodti = 5.0 * p.rkconv * ptsphy;
+  c.zckcodtla = c.zckcodtl / 100.0;
+  c.zckcodtia = c.zckcodti / 100.0;
+  c.zcons2 = 1.0 / (ptsphy * p.rg);
+  c.zcons3 = p.rlvtt / p.rcpd;
+  c.zmeltp2 = p.rtt + 2.0;
+  c.zqtmst = 1.0 / ptsphy;
+  c.evap = (p.levapls2 || p.ldrain1d) ? 1 : 0;
+  // cloudsc2.F90:505-509,522-526
+  c.zlcrit_l = c.evap ? 1.9 * p.rclcrit : p.rclcrit * 2.0;
+  c.zlcrit_i = c.evap ? 1.e-04 : p.rclcrit * 2.0;
+  c.rcpd_r = 1.0 / p.rcpd;
+  c.zlcrit_l_r = 1.0 / c.zlcrit_l;
+  c.zlcrit_i_r = 1.0 / c.zlcrit_i;
+  c.zcons2_r = ptsphy * p.rg;
+  c.rvtmp2_zero = (p.rvtmp2 == 0.0) ? 1 : 0;
+  c.zzz0 = 1.0 / (p.rcpd + p.rcpd * p.rvtmp2 * 0.0);
+  c.zlfdcp0_r = 1.0 / (p.rlmlt * c.zzz0);
+  c.lregcl = p.lregcl ? 1 : 0;
+  c.nlev = p.nlev;
+  fill_stage_blocks(c);
+  return c;
+}
+
 // Raw inputs of one level (dummy arguments of CLOUDSC2 at (JL,JK); cloudsc2.F90:124-143).
 struct LevelIn {
   real_t paph_k, paph_k1;  // PAPHP1(JK), PAPHP1(JK+1)
@@ -210,6 +247,8 @@ struct LevelOut {
 // Per-level, column-independent values prepared on the host.
 typedef const C2_CONST_AS Consts* ConstsP;
 
+#define C2_CONSTS(a) (&(a)->c)
+
 // A wave has 102 SGPRs; the ~40 fp64 constants of a level plus the field pointers do not fit, and left to itself the
 // compiler sinks every constant's s_load next to its use (one exposed scalar-cache latency per constant: 42
 // `s_waitcnt lgkmcnt(0)` per level, half of the wave's lifetime).  The constants are therefore grouped by the stage that
@@ -223,7 +262,7 @@ typedef const C2_CONST_AS Consts* ConstsP;
 #ifndef C2_PIN_DEF
 #define C2_PIN_DEF 0
 #endif
-#if C2_PIN_DEF
+#if C2_PIN_DEF == 1
 #define C2_PIN8(b) asm volatile("" : "+s"((b).v[0]), "+s"((b).v[1]), "+s"((b).v[2]), "+s"((b).v[3]), "+s"((b).v[4]), \
                                  "+s"((b).v[5]), "+s"((b).v[6]), "+s"((b).v[7]))
 #define C2_PIN2(x, y) asm volatile("" : "+s"(x), "+s"(y))
@@ -396,11 +435,16 @@ struct LevelTraj {
 // Trajectory of one level.  cloudsc2.F90:253-279 (first guess) + :343-723.
 // Same statements as the reference, with the quotients rewritten on shared reciprocals (see c2_rcp above).
 // ---------------------------------------------------------------------------------------------------------
-template <bool P>
+// EVAP is Consts::evap lifted to compile time (the launchers dispatch on it): LEVAPLS2/LDRAIN1D are off in every
+// shipped configuration, and with the evaporation branch merely skipped at run time its live ranges still cost
+// ~60 VGPRs (one wave per SIMD less in the NL kernel).  With EVAP=false t.llo2 is a compile-time false, which also
+// removes the branch's TL and AD statements.
+template <bool P, bool EVAP>
 C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const LevelIn& x, Carry& cy,
                          LevelTraj& t, LevelOut& o) {
   const real_t zqmax = 0.5, zeps2 = 1.e-10;
-  const int rvtmp2_zero = c->rvtmp2_zero, evap = c->evap;
+  const int rvtmp2_zero = c->rvtmp2_zero;
+  const bool evap = EVAP;
 
   // ---- blocks k0 (first guess, entry reciprocals, saturation pressure) and k1 (dqs/dT, critical RH, convection) ----
   StageBlock k0, k1;

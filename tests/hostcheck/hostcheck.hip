@@ -10,40 +10,23 @@
 
 using namespace cloudsc2;
 
-// same derivation as make_consts()/get_tables() in cloudsc2_kernels.hip
-static Consts hc_consts(const cloudsc2_params& p, double ptsphy) {
-  Consts c;
-  c.rg = p.rg; c.rd = p.rd; c.rcpd = p.rcpd; c.retv = p.retv; c.rlvtt = p.rlvtt; c.rlstt = p.rlstt;
-  c.rlmlt = p.rlmlt; c.rtt = p.rtt;
-  c.r2es = p.r2es; c.r3les = p.r3les; c.r3ies = p.r3ies; c.r4les = p.r4les; c.r4ies = p.r4ies;
-  c.r5les = p.r5les; c.r5ies = p.r5ies; c.r5alvcp = p.r5alvcp; c.r5alscp = p.r5alscp;
-  c.ralvdcp = p.ralvdcp; c.ralsdcp = p.ralsdcp;
-  c.rtwat = p.rtwat; c.rtice = p.rtice; c.rtwat_rtice_r = p.rtwat_rtice_r; c.rvtmp2 = p.rvtmp2;
-  c.rlmin = p.rlmin; c.rpecons = p.rpecons; c.rlptrc = p.rlptrc;
-  c.ptsphy = ptsphy;
-  c.zckcodtl = 2.0 * p.rkconv * ptsphy;
-  c.zckcodti = 5.0 * p.rkconv * ptsphy;
-  c.zckcodtla = c.zckcodtl / 100.0;
-  c.zckcodtia = c.zckcodti / 100.0;
-  c.zcons2 = 1.0 / (ptsphy * p.rg);
-  c.zcons3 = p.rlvtt / p.rcpd;
-  c.zmeltp2 = p.rtt + 2.0;
-  c.zqtmst = 1.0 / ptsphy;
-  c.evap = (p.levapls2 || p.ldrain1d) ? 1 : 0;
-  c.zlcrit_l = c.evap ? 1.9 * p.rclcrit : p.rclcrit * 2.0;
-  c.zlcrit_i = c.evap ? 1.e-04 : p.rclcrit * 2.0;
-  c.rcpd_r = 1.0 / p.rcpd;
-  c.zlcrit_l_r = 1.0 / c.zlcrit_l;
-  c.zlcrit_i_r = 1.0 / c.zlcrit_i;
-  c.zcons2_r = ptsphy * p.rg;
-  c.rvtmp2_zero = (p.rvtmp2 == 0.0) ? 1 : 0;
-  c.zzz0 = 1.0 / (p.rcpd + p.rcpd * p.rvtmp2 * 0.0);
-  c.zlfdcp0_r = 1.0 / (p.rlmlt * c.zzz0);
-  c.lregcl = p.lregcl ? 1 : 0;
-  c.nlev = p.nlev;
-  fill_stage_blocks(c);
-  return c;
+static Consts hc_consts(const cloudsc2_params& p, double ptsphy) { return make_consts(p, ptsphy); }
+
+// run-time flag word -> compile-time variant
+template <template <unsigned> class Fn, unsigned N, unsigned F = 0, class A>
+static void hc_dispatch(unsigned f, long long gc, const A* a) {
+  if constexpr (F < N) {
+    if (f == F) Fn<F>::run(gc, a);
+    else hc_dispatch<Fn, N, F + 1>(f, gc, a);
+  }
 }
+template <unsigned F> struct HcNl { static void run(long long gc, const NlArgs* a) { nl_column<F>(gc, a); } };
+template <unsigned F> struct HcTl { static void run(long long gc, const TlArgs* a) { tl_column<F>(gc, a); } };
+template <unsigned F> struct HcAd {
+  static void run(long long gc, const AdArgs* a) { nl_column<F | C2F_CKPT>(gc, &a->nl); ad_reverse_column<F>(gc, a); }
+};
+
+// same derivation as get_tables() in cloudsc2_kernels.hip
 
 static void hc_tables(const cloudsc2_params& p, LevelTab& tab, Geom& g) {
   memset(&tab, 0, sizeof(tab));
@@ -105,21 +88,10 @@ int hostcheck_nl(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev
   a.tab = &tab;
   a.s = Strides{0, 0, 0, 0, 0};
   hc_in(*in, a.s, a.in); hc_out(*out, a.s, a.out);
-  a.zero_plane = zero_plane.ptr; a.zero_stride = zero_plane.block_stride; a.lam = lam;
-  const bool hq = in->qsat.ptr != nullptr, pt = lam != 0.0;
-  for (long long gc = 0; gc < a.g.ncols_pad; ++gc) {
-    if (g_hc_precise) {
-      if (hq && pt) nl_column<true, true, true>(gc, &a);
-      else if (hq) nl_column<true, false, true>(gc, &a);
-      else if (pt) nl_column<false, true, true>(gc, &a);
-      else nl_column<false, false, true>(gc, &a);
-    } else {
-      if (hq && pt) nl_column<true, true, false>(gc, &a);
-      else if (hq) nl_column<true, false, false>(gc, &a);
-      else if (pt) nl_column<false, true, false>(gc, &a);
-      else nl_column<false, false, false>(gc, &a);
-    }
-  }
+  a.zero_plane = zero_plane.ptr; a.zero_stride = zero_plane.block_stride; a.lam = lam; a.ckpt = nullptr;
+  unsigned f = (in->qsat.ptr ? C2F_QSAT : 0u) | (lam != 0.0 ? C2F_PERT : 0u) | (g_hc_precise ? C2F_PRECISE : 0u) |
+               (a.c.evap ? C2F_EVAP : 0u);
+  for (long long gc = 0; gc < a.g.ncols_pad; ++gc) hc_dispatch<HcNl, 16>(f, gc, &a);
   return 0;
 }
 
@@ -132,32 +104,28 @@ int hostcheck_tl(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev
   a.tab = &tab;
   a.s = Strides{0, 0, 0, 0, 0}; a.sp = Strides{0, 0, 0, 0, 0};
   hc_in(*in, a.s, a.in); hc_out(*out, a.s, a.out); hc_in(*din, a.sp, a.din); hc_out(*dout, a.sp, a.dout);
-  for (long long gc = 0; gc < a.g.ncols_pad; ++gc) {
-    if (g_hc_precise) { if (in->qsat.ptr) tl_column<true, true, true>(gc, &a); else tl_column<false, true, true>(gc, &a); }
-    else { if (in->qsat.ptr) tl_column<true, false, true>(gc, &a); else tl_column<false, false, true>(gc, &a); }
-  }
+  unsigned f = (in->qsat.ptr ? C2F_QSAT : 0u) | C2F_TRAJ | (g_hc_precise ? C2F_PRECISE : 0u) | (a.c.evap ? C2F_EVAP : 0u);
+  for (long long gc = 0; gc < a.g.ncols_pad; ++gc) hc_dispatch<HcTl, 16>(f, gc, &a);
   return 0;
 }
 
 int hostcheck_ad(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot, const cloudsc2_inputs* in,
                  const cloudsc2_outputs* out, const cloudsc2_inputs* ain, const cloudsc2_outputs* aout, double* scratch) {
   AdArgs a;
-  a.g = hc_geom(nproma, nlev, ngptot);
-  a.c = hc_consts(*prm, ptsphy);
-  LevelTab tab; hc_tables(*prm, tab, a.g);
-  a.tab = &tab;
-  a.s = Strides{0, 0, 0, 0, 0}; a.sa = Strides{0, 0, 0, 0, 0};
+  a.nl.g = hc_geom(nproma, nlev, ngptot);
+  a.nl.c = hc_consts(*prm, ptsphy);
+  LevelTab tab; hc_tables(*prm, tab, a.nl.g);
+  a.nl.tab = &tab;
+  a.nl.s = Strides{0, 0, 0, 0, 0}; a.sa = Strides{0, 0, 0, 0, 0};
   InPtrs aip_c;
-  hc_in(*in, a.s, a.in); hc_out(*out, a.s, a.out); hc_in(*ain, a.sa, aip_c); hc_out(*aout, a.sa, a.aout);
+  hc_in(*in, a.nl.s, a.nl.in); hc_out(*out, a.nl.s, a.nl.out); hc_in(*ain, a.sa, aip_c); hc_out(*aout, a.sa, a.aout);
   a.ain.paph = ain->paph.ptr; a.ain.pap = ain->pap.ptr; a.ain.q = ain->q.ptr; a.ain.qsat = ain->qsat.ptr; a.ain.t = ain->t.ptr;
   a.ain.l = ain->l.ptr; a.ain.i = ain->i.ptr; a.ain.lude = ain->lude.ptr; a.ain.lu = ain->lu.ptr; a.ain.mfu = ain->mfu.ptr;
   a.ain.mfd = ain->mfd.ptr; a.ain.gt = ain->gtent.ptr; a.ain.gq = ain->gtenq.ptr; a.ain.gl = ain->gtenl.ptr;
   a.ain.gi = ain->gteni.ptr; a.ain.supsat = ain->supsat.ptr;
-  a.scratch = scratch;
-  for (long long gc = 0; gc < a.g.ncols_pad; ++gc) {
-    if (g_hc_precise) { if (in->qsat.ptr) ad_column<true, true>(gc, &a); else ad_column<false, true>(gc, &a); }
-    else { if (in->qsat.ptr) ad_column<true, false>(gc, &a); else ad_column<false, false>(gc, &a); }
-  }
+  a.nl.zero_plane = nullptr; a.nl.zero_stride = 0; a.nl.lam = 0.0; a.nl.ckpt = scratch;
+  unsigned f = (in->qsat.ptr ? C2F_QSAT : 0u) | (g_hc_precise ? C2F_PRECISE : 0u) | (a.nl.c.evap ? C2F_EVAP : 0u);
+  for (long long gc = 0; gc < a.nl.g.ncols_pad; ++gc) hc_dispatch<HcAd, 8>(f, gc, &a);
   return 0;
 }
 
