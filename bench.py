@@ -118,7 +118,7 @@ def main():
     if args.kernel == "nl":
         step = lambda: ds.nl(prm, stream)  # noqa: E731
         bpc = c2.bytes_per_column(st.nlev, "nl_driver")
-        kname = "nl_kernel<false,false> (SATUR + CLOUDSC2)"
+        kname = "nl_kernel<0> (SATUR + CLOUDSC2 fused, fast math, no evaporation branch)"
     else:
         ds.satur(prm, stream)
         inc = ds.increments(zero_supsat=(args.kernel == "ad"))
@@ -126,13 +126,13 @@ def main():
         if args.kernel == "tl":
             step = lambda: ds.tl(prm, inc, dout, stream)  # noqa: E731
             bpc = c2.bytes_per_column(st.nlev, "tl")
-            kname = "tl_kernel<true> (CLOUDSC2TL)"
+            kname = "tl_kernel<C2F_QSAT> (CLOUDSC2TL, trajectory recomputed, not stored)"
         else:
             ds.tl(prm, inc, dout, stream)
             scratch = ds.new_scratch()
             step = lambda: ds.ad(prm, inc, dout, scratch, stream)  # noqa: E731
             bpc = c2.bytes_per_column(st.nlev, "ad") + 2 * 8 * st.nlev  # + carry checkpoint plane (write + read)
-            kname = "ad_kernel<true> (CLOUDSC2AD)"
+            kname = "ad_kernel<C2F_QSAT> (CLOUDSC2AD: trajectory pass + reverse pass)"
 
     for _ in range(args.warmup):
         step()
@@ -168,7 +168,9 @@ def main():
         if os.path.isdir(os.path.join(ROOT, "profiles")) else []
     if pmc_files:
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_files[-1])))
+            pmcs = [json.load(open(os.path.join(ROOT, "profiles", f))) for f in pmc_files]
+            same = [p for p in pmcs if p.get("ngptot") == args.ngptot]  # prefer the pass taken at this launch size
+            pmc = (same or pmcs)[-1]
             traffic = pmc["kernels"][args.kernel]["traffic_bytes"] / pmc["ngptot"] * args.ngptot
         except (KeyError, ValueError, OSError):
             traffic = None
