@@ -111,13 +111,14 @@ def main():
     tab = c2.synthetic_table()
     prm = c2.default_params(c2.ceta_from_table(tab), lregcl=(args.kernel == "ad"))
     col0 = rank * args.ngptot  # weak scaling: rank r owns global columns [r*NGPTOT, (r+1)*NGPTOT)
-    st = c2.state_from_table(tab, args.nproma, args.ngptot, col0=col0)
-    ds = c2.DeviceState(st, dev)
+    # the state is tiled on the device from the 100-column table (cloudsc2_expand_launch): no host copy of it exists
+    ds = c2.DeviceState.from_table(tab, args.nproma, args.ngptot, dev, start=col0)
+    nlev = ds.nlev
     stream = torch.cuda.current_stream(dev)
 
     if args.kernel == "nl":
         step = lambda: ds.nl(prm, stream)  # noqa: E731
-        bpc = c2.bytes_per_column(st.nlev, "nl_driver")
+        bpc = c2.bytes_per_column(nlev, "nl_driver")
         kname = "nl_kernel<0> (SATUR + CLOUDSC2 fused, fast math, no evaporation branch)"
     else:
         ds.satur(prm, stream)
@@ -125,13 +126,13 @@ def main():
         dout = c2.FlatFields("out", ds.nb, ds.nlev, ds.nproma, dev)
         if args.kernel == "tl":
             step = lambda: ds.tl(prm, inc, dout, stream)  # noqa: E731
-            bpc = c2.bytes_per_column(st.nlev, "tl")
+            bpc = c2.bytes_per_column(nlev, "tl")
             kname = "tl_kernel<C2F_QSAT> (CLOUDSC2TL, trajectory recomputed, not stored)"
         else:
             ds.tl(prm, inc, dout, stream)
             scratch = ds.new_scratch()
             step = lambda: ds.ad(prm, inc, dout, scratch, stream)  # noqa: E731
-            bpc = c2.bytes_per_column(st.nlev, "ad") + 2 * 8 * st.nlev  # + carry checkpoint plane (write + read)
+            bpc = c2.bytes_per_column(nlev, "ad") + 2 * 8 * nlev  # + carry checkpoint plane (write + read)
             kname = "ad_kernel<C2F_QSAT> (CLOUDSC2AD: trajectory pass + reverse pass)"
 
     for _ in range(args.warmup):
@@ -184,7 +185,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"CLOUDSC2 {args.kernel.upper()} fp64, NGPTOT={args.ngptot} columns per GPU, NLEV=137, "
                                f"NPROMA={args.nproma} (BASELINE.json configs[1])",
-                   "ngptot_per_gpu": args.ngptot, "nlev": st.nlev, "nproma": args.nproma,
+                   "ngptot_per_gpu": args.ngptot, "nlev": nlev, "nproma": args.nproma,
                    "parallelism": f"columns sharded over {world} GPU(s), no data-path collective"},
         "roofline": roofline,
     }

@@ -117,7 +117,19 @@ def _load() -> C.CDLL:
     lib.cloudsc2_release_workspace.restype = None
     lib.cloudsc2_taylor_verdict.argtypes = [dp, C.POINTER(C.c_int)]
     lib.cloudsc2_adjoint_verdict.argtypes = [C.c_double]
-    for name in ("cloudsc2_nl_launch", "cloudsc2_satur_launch", "cloudsc2_tl_launch", "cloudsc2_ad_launch",
+    expand_args = [dp, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_longlong, Field]
+    lib.cloudsc2_expand_launch.argtypes = expand_args + [C.c_void_p]
+    lib.cloudsc2_validate_workspace_doubles.restype = C.c_int
+    lib.cloudsc2_validate_launch.argtypes = expand_args + [dp, dp, C.c_void_p]
+    lib.cloudsc2_expand_offsets.argtypes = [C.c_int, C.c_longlong, C.c_longlong, C.c_int, C.c_int, C.POINTER(C.c_longlong),
+                                            C.POINTER(C.c_int)]
+    lib.cloudsc2_expand_offsets.restype = None
+    lib.cloudsc2_validate_relerr.argtypes = [C.c_double, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.cloudsc2_validate_relerr.restype = C.c_double
+    lib.cloudsc2_validate_format.argtypes = [C.c_char_p, C.c_int, dp, C.c_longlong, C.c_char_p, C.c_int]
+    lib.cloudsc2_validate_header.argtypes = [C.c_char_p, C.c_int]
+    for name in ("cloudsc2_expand_launch", "cloudsc2_validate_launch", "cloudsc2_validate_format", "cloudsc2_validate_header",
+                 "cloudsc2_nl_launch", "cloudsc2_satur_launch", "cloudsc2_tl_launch", "cloudsc2_ad_launch",
                  "cloudsc2_taylor_sums_launch", "cloudsc2_adjoint_norms_launch", "cloudsc2_nl_run",
                  "cloudsc2_tl_taylor_run", "cloudsc2_ad_symmetry_run", "cloudsc2_taylor_verdict",
                  "cloudsc2_adjoint_verdict"):
@@ -132,7 +144,9 @@ EXPORTED = ("cloudsc2_params_default", "cloudsc2_last_error", "cloudsc2_device_a
             "cloudsc2_get_math_mode", "cloudsc2_nl_launch",
             "cloudsc2_satur_launch", "cloudsc2_tl_launch", "cloudsc2_ad_launch", "cloudsc2_taylor_sums_launch",
             "cloudsc2_adjoint_norms_launch", "cloudsc2_nl_run", "cloudsc2_tl_taylor_run", "cloudsc2_ad_symmetry_run",
-            "cloudsc2_release_workspace", "cloudsc2_taylor_verdict", "cloudsc2_adjoint_verdict")
+            "cloudsc2_release_workspace", "cloudsc2_taylor_verdict", "cloudsc2_adjoint_verdict",
+            "cloudsc2_expand_launch", "cloudsc2_validate_workspace_doubles", "cloudsc2_validate_launch",
+            "cloudsc2_expand_offsets", "cloudsc2_validate_relerr", "cloudsc2_validate_format", "cloudsc2_validate_header")
 
 
 def check(rc: int) -> None:
@@ -173,3 +187,24 @@ def taylor_verdict(znormg) -> tuple[bool, int]:
 
 def adjoint_verdict(znormg: float) -> bool:
     return bool(lib.cloudsc2_adjoint_verdict(float(znormg)))
+
+
+def expand_offsets(klon: int, ngptot: int, ngptotg: int = 0, irank: int = 0, numproc: int = 1):
+    """GET_OFFSETS (expand_mod.F90:30-46): (0-based first table column, tiling period) of a rank."""
+    start, period = C.c_longlong(), C.c_int()
+    lib.cloudsc2_expand_offsets(klon, ngptot, ngptotg, irank, numproc, C.byref(start), C.byref(period))
+    return start.value, period.value
+
+
+def validate_line(name: str, ndim: int, stats, ngptotg: int) -> str:
+    """The line ERROR_PRINT writes for one variable (validate_mod.F90:263-296)."""
+    buf = C.create_string_buffer(200)
+    st = (C.c_double * 5)(*[float(x) for x in stats])
+    check(lib.cloudsc2_validate_format(name.encode(), ndim, st, int(ngptotg), buf, 200))
+    return buf.value.decode()
+
+
+def validate_header() -> str:
+    buf = C.create_string_buffer(200)
+    check(lib.cloudsc2_validate_header(buf, 200))
+    return buf.value.decode()

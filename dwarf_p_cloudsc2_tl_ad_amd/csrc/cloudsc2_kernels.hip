@@ -9,9 +9,11 @@
 // appear only in the two test-norm kernels.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <cmath>
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
+#include <algorithm>
 #include <array>
 #include <atomic>
 #include <utility>
@@ -183,6 +185,88 @@ C2_VARIANT_TABLE(g_nl_kernels, nl_kernel, NlArgs, 32, !((F & C2F_PERT) && (F & C
 C2_VARIANT_TABLE(g_tl_kernels, tl_kernel, TlArgs, 16, true)
 C2_VARIANT_TABLE(g_ad_reverse_kernels, ad_reverse_kernel, AdArgs, 8, !C2_AD_FUSED)
 C2_VARIANT_TABLE(g_ad_kernels, ad_kernel, AdArgs, 8, C2_AD_FUSED != 0)
+
+// ---------------------------------------------------------------------------------------------------------
+// Data-format kernels either side of the path: the input file holds KLON (=100) columns,
+// the model state is their periodic tiling into NPROMA blocks (expand_mod.F90:270-335), and the validator compares
+// the outputs with a KLON-column reference (validate_mod.F90:165-261).  Both work from the small table on the
+// device, so a 1M-column state never exists on the host and the reference is never expanded at all.
+// ---------------------------------------------------------------------------------------------------------
+// field(jl, jk, jm, ibl) = table((start + ibl*NPROMA + jl) mod period, jk, jm) for active columns, 0 for the padded
+// tail of the last block (expand_mod.F90:283-296; `start`,`period` = get_offsets, :30-46).
+__global__ void __launch_bounds__(256)
+expand_kernel(const double* __restrict__ table, int klon, int period, long long start, int nlevx, int ndim, int nproma,
+              long long ngptot, long long nblocks, double* __restrict__ field, long long block_stride) {
+  const long long per_block = (long long)nproma * nlevx * ndim;
+  const long long total = per_block * nblocks;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long ibl = e / per_block;
+    const long long r = e - ibl * per_block;
+    const int jl = (int)(r % nproma);
+    const long long lev = r / nproma;  // jk + nlevx*jm
+    const long long g = ibl * nproma + jl;
+    double v = 0.0;
+    if (g < ngptot) v = table[(start + g) % period + (long long)klon * lev];
+    field[ibl * block_stride + r] = v;
+  }
+}
+
+// Per-workgroup partial statistics of VALIDATE_R2/R3 (validate_mod.F90:165-261): min and max of FIELD over whole
+// blocks (padding included, like MINVAL(FIELD(:,:,B))), max |FIELD-REF|, sum |FIELD-REF|, sum |REF| over the active
+// columns.  part[5*blockIdx.x + {0..4}]; a second launch folds the partials in a fixed order (deterministic sums).
+__global__ void __launch_bounds__(256)
+validate_partial_kernel(const double* __restrict__ table, int klon, int period, long long start, int nlevx, int ndim,
+                        int nproma, long long ngptot, long long nblocks, const double* __restrict__ field,
+                        long long block_stride, double* __restrict__ part) {
+  const long long per_block = (long long)nproma * nlevx * ndim;
+  const long long total = per_block * nblocks;
+  double vmin = INFINITY, vmax = -INFINITY, emax = 0.0, esum = 0.0, rsum = 0.0;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long ibl = e / per_block;
+    const long long r = e - ibl * per_block;
+    const int jl = (int)(r % nproma);
+    const long long lev = r / nproma;
+    const long long g = ibl * nproma + jl;
+    const double f = field[ibl * block_stride + r];
+    vmin = fmin(vmin, f);
+    vmax = fmax(vmax, f);
+    if (g < ngptot) {
+      const double ref = table[(start + g) % period + (long long)klon * lev];
+      const double d = fabs(f - ref);
+      emax = fmax(emax, d);
+      esum += d;
+      rsum += fabs(ref);
+    }
+  }
+  __shared__ double red[5][4];
+  for (int off = 32; off > 0; off >>= 1) {
+    vmin = fmin(vmin, __shfl_down(vmin, off, 64));
+    vmax = fmax(vmax, __shfl_down(vmax, off, 64));
+    emax = fmax(emax, __shfl_down(emax, off, 64));
+    esum += __shfl_down(esum, off, 64);
+    rsum += __shfl_down(rsum, off, 64);
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][w] = vmin; red[1][w] = vmax; red[2][w] = emax; red[3][w] = esum; red[4][w] = rsum; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 4; ++i) {
+      red[0][0] = fmin(red[0][0], red[0][i]); red[1][0] = fmax(red[1][0], red[1][i]); red[2][0] = fmax(red[2][0], red[2][i]);
+      red[3][0] += red[3][i]; red[4][0] += red[4][i];
+    }
+    for (int k = 0; k < 5; ++k) part[5 * (long long)blockIdx.x + k] = red[k][0];
+  }
+}
+
+__global__ void validate_final_kernel(const double* __restrict__ part, int nparts, double* __restrict__ stats) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double vmin = INFINITY, vmax = -INFINITY, emax = 0.0, esum = 0.0, rsum = 0.0;
+  for (int i = 0; i < nparts; ++i) {
+    vmin = fmin(vmin, part[5 * i + 0]); vmax = fmax(vmax, part[5 * i + 1]); emax = fmax(emax, part[5 * i + 2]);
+    esum += part[5 * i + 3]; rsum += part[5 * i + 4];
+  }
+  stats[0] = vmin; stats[1] = vmax; stats[2] = emax; stats[3] = esum; stats[4] = rsum;
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // Test-norm kernels
@@ -535,6 +619,51 @@ int cloudsc2_ad_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// state expansion / validation launchers
+// ---------------------------------------------------------------------------------------------------------
+static int check_expand_args(const double* table, int klon, int period, long long start, int nlevx, int ndim, int nproma,
+                             long long ngptot, cloudsc2_field field, long long* nblocks) {
+  if (!device_ok()) return fail(CLOUDSC2_ENODEVICE, "no HIP device available (this library has no CPU path)");
+  if (!table || !field.ptr) return fail(CLOUDSC2_EINVAL, "NULL argument");
+  if (klon < 1 || period < 1 || period > klon || start < 0 || nlevx < 1 || ndim < 1 || nproma < 1 || ngptot < 1)
+    return fail(CLOUDSC2_EINVAL, "expand/validate: need 1 <= period <= KLON, start >= 0, positive dimensions");
+  *nblocks = (ngptot + nproma - 1) / nproma;
+  if (field.block_stride < (long long)nproma * nlevx * ndim)
+    return fail(CLOUDSC2_EINVAL, "expand/validate: block stride smaller than NPROMA*NLEV*NDIM");
+  return 0;
+}
+
+int cloudsc2_expand_launch(const double* table, int klon, int period, long long start, int nlevx, int ndim, int nproma,
+                           long long ngptot, cloudsc2_field field, void* stream) {
+  long long nblocks;
+  int rc = check_expand_args(table, klon, period, start, nlevx, ndim, nproma, ngptot, field, &nblocks);
+  if (rc) return rc;
+  const long long total = nblocks * nproma * nlevx * ndim;
+  const unsigned grid = (unsigned)std::min<long long>((total + 255) / 256, 256 * 32);
+  hipLaunchKernelGGL(expand_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, table, klon, period, start, nlevx, ndim,
+                     nproma, ngptot, nblocks, field.ptr, field.block_stride);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int cloudsc2_validate_workspace_doubles(void) { return 5 * 2048; }
+
+int cloudsc2_validate_launch(const double* table, int klon, int period, long long start, int nlevx, int ndim, int nproma,
+                             long long ngptot, cloudsc2_field field, double* workspace, double* stats, void* stream) {
+  long long nblocks;
+  int rc = check_expand_args(table, klon, period, start, nlevx, ndim, nproma, ngptot, field, &nblocks);
+  if (rc) return rc;
+  if (!workspace || !stats) return fail(CLOUDSC2_EINVAL, "NULL argument");
+  const long long total = nblocks * nproma * nlevx * ndim;
+  const int nparts = (int)std::min<long long>((total + 255) / 256, 2048);
+  hipLaunchKernelGGL(validate_partial_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, table, klon, period, start,
+                     nlevx, ndim, nproma, ngptot, nblocks, (const double*)field.ptr, field.block_stride, workspace);
+  hipLaunchKernelGGL(validate_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double*)workspace, nparts, stats);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 static int ten_ptrs(const cloudsc2_outputs* o, int nlev, TenPtrs& t) {
   // order of the ERROR_NORM calls, cloudsc_driver_tl_mod.F90:233-242
   const cloudsc2_field* f[10] = {&o->tent, &o->tenq, &o->tenl, &o->teni, &o->clc,
@@ -592,6 +721,68 @@ int cloudsc2_adjoint_norms_launch(int nproma, int nlev, int ngptot, const clouds
                        qsat->block_stride, xp, norms, g.ncols_pad, blockmax);
     HIP_TRY(hipGetLastError());
   }
+  return 0;
+}
+
+void cloudsc2_expand_offsets(int klon, long long ngptot, long long ngptotg, int irank, int numproc, long long* start,
+                             int* period) {
+  // expand_mod.F90:30-46: ranks read different table columns only when the table covers the whole global domain
+  const bool use_offset = ngptotg > 0 && (long long)klon >= ngptotg;
+  long long st = 0;
+  if (use_offset) st = (long long)irank * ((ngptotg - 1) / (numproc > 0 ? numproc : 1) + 1);
+  if (start) *start = st;
+  if (period) *period = (int)std::min<long long>(klon, ngptot);
+}
+
+double cloudsc2_validate_relerr(double esum, double rsum, int* iopt, int* warn) {
+  // validate_mod.F90:272-289
+  const double zeps = 2.220446049250313e-16;
+  double zrel; int io;
+  if (esum < zeps) { zrel = 0.0; io = 1; }
+  else if (rsum < zeps) { zrel = esum / (1.0 + rsum); io = 2; }
+  else { zrel = esum / rsum; io = 3; }
+  if (iopt) *iopt = io;
+  if (warn) *warn = zrel > 10.0 * zeps ? 1 : 0;
+  return 100.0 * zrel;
+}
+
+// Fortran E20.13: sign, "0.", 13 digits, "E", sign, two exponent digits (three without the E when |exp| > 99)
+static void fortran_e20_13(double v, char out[24]) {
+  if (!std::isfinite(v)) { snprintf(out, 24, "%20s", std::isnan(v) ? "NaN" : (v > 0 ? "Infinity" : "-Infinity")); return; }
+  char tmp[40];
+  snprintf(tmp, sizeof tmp, "%.12E", fabs(v));  // d.ddddddddddddE+xx
+  int ex = atoi(strchr(tmp, 'E') + 1);
+  char digits[16];
+  digits[0] = tmp[0];
+  memcpy(digits + 1, tmp + 2, 12);
+  digits[13] = 0;
+  if (v != 0.0) ex += 1;
+  char body[32];
+  if (ex > 99 || ex < -99) snprintf(body, sizeof body, "%s0.%s%c%03d", v < 0 ? "-" : "", digits, ex < 0 ? '-' : '+', abs(ex));
+  else snprintf(body, sizeof body, "%s0.%sE%c%02d", v < 0 ? "-" : "", digits, ex < 0 ? '-' : '+', abs(ex));
+  snprintf(out, 24, "%20s", body);
+}
+
+int cloudsc2_validate_format(const char* name, int ndim, const double stats[5], long long ngptotg, char* buf, int buflen) {
+  if (!name || !stats || !buf || buflen < 160 || ngptotg < 1) return fail(CLOUDSC2_EINVAL, "validate_format: bad argument");
+  int iopt, warn;
+  const double zrel = cloudsc2_validate_relerr(stats[3], stats[4], &iopt, &warn);
+  const double cols[5] = {stats[0], stats[1], stats[2], stats[3] / (double)ngptotg, zrel};
+  int n = snprintf(buf, buflen, " %20.20s %1dD%1d", name, ndim, iopt);  // A20 right-justifies
+  for (double c : cols) {
+    char e[24];
+    fortran_e20_13(c, e);
+    n += snprintf(buf + n, buflen - n, " %s", e);
+  }
+  snprintf(buf + n, buflen - n, "%s", warn ? " !!!!" : "     ");  // CHARACTER(LEN=5) clwarn
+  return 0;
+}
+
+int cloudsc2_validate_header(char* buf, int buflen) {
+  if (!buf || buflen < 160) return fail(CLOUDSC2_EINVAL, "validate_header: bad argument");
+  // print '(1X,A20,1X,A3,5(1X,A20))' -- character items are right-justified in A20 / A3
+  snprintf(buf, buflen, " %20s %3s %20s %20s %20s %20s %20s", "Variable", "Dim", "MinValue", "MaxValue", "AbsMaxErr",
+           "AvgAbsErr/GP", "MaxRelErr-%");
   return 0;
 }
 

@@ -13,7 +13,7 @@ import ctypes as C
 import numpy as np
 
 from . import binding as B
-from .state import PLANE_Q, PLANE_QI, PLANE_QL, PLANE_QV, PLANE_T, Cloudsc2State, nblocks_of
+from .state import PLANE_A, PLANE_Q, PLANE_QI, PLANE_QL, PLANE_QV, PLANE_T, Cloudsc2State, nblocks_of
 
 _dp = C.POINTER(C.c_double)
 
@@ -124,6 +124,73 @@ class DeviceState:
             setattr(self, n, torch.from_numpy(getattr(st, n)).to(self.device))
         self.QSAT = torch.zeros_like(self.PT)
         self._keep = []
+
+    @classmethod
+    def from_table(cls, tab: dict, nproma: int, ngptot: int, device="cuda:0", start: int = 0, period: int | None = None,
+                   stream=None) -> "DeviceState":
+        """CLOUDSC2_ARRAY_STATE_LOAD (cloudsc2_array_state_mod.F90:153-203) without a host copy of the state: the
+        KLON-column table is uploaded (a few MB) and tiled into the NPROMA-blocked arrays by cloudsc2_expand_launch;
+        outputs are zero-initialised (FIELD_INIT, :186-190).  ``start``/``period``: binding.expand_offsets."""
+        import torch
+
+        self = cls.__new__(cls)
+        self.torch = torch
+        self.device = torch.device(device)
+        nlev, klon = tab["PT"].shape
+        self.nproma, self.nlev, self.ngptot, self.ptsphy = nproma, nlev, ngptot, float(tab["PTSPHY"])
+        self.nb = nblocks_of(ngptot, nproma)
+        self._keep = []
+        period = klon if period is None else period
+        z = lambda *shape: torch.zeros(shape, dtype=torch.float64, device=self.device)  # noqa: E731
+        for n in self.FULL:
+            setattr(self, n, z(self.nb, nlev, nproma))
+        for n in self.HALF:
+            setattr(self, n, z(self.nb, nlev + 1, nproma))
+        self.B_CML, self.B_LOC, self.PCLV = z(self.nb, 8, nlev, nproma), z(self.nb, 8, nlev, nproma), z(self.nb, 5, nlev, nproma)
+        self.QSAT = z(self.nb, nlev, nproma)
+        S, H = nproma * nlev, nproma * (nlev + 1)
+        jobs = [(n, getattr(self, n), 0, S if tab[n].shape[0] == nlev else H)
+                for n in ("PT", "PQ", "PAP", "PAPH", "PLU", "PLUDE", "PMFU", "PMFD", "PA", "PSUPSAT")]
+        jobs += [("TENDENCY_CML_T", self.B_CML, PLANE_T * S, 8 * S), ("TENDENCY_CML_Q", self.B_CML, PLANE_Q * S, 8 * S),
+                 ("TENDENCY_CML_QL", self.B_CML, PLANE_QL * S, 8 * S), ("TENDENCY_CML_QI", self.B_CML, PLANE_QI * S, 8 * S),
+                 ("PCLV_QL", self.PCLV, 0, 5 * S), ("PCLV_QI", self.PCLV, S, 5 * S)]
+        for name, dst, off, stride in jobs:
+            src = torch.from_numpy(np.ascontiguousarray(tab[name], dtype=np.float64)).to(self.device)
+            self._keep.append(src)
+            B.check(B.lib.cloudsc2_expand_launch(C.cast(src.data_ptr(), C.POINTER(C.c_double)), klon, period, start,
+                                                 src.shape[0], 1, nproma, ngptot, _fld(dst, off, stride), self._stream(stream)))
+        return self
+
+    def validate(self, ref: dict, ngptotg: int | None = None, start: int = 0, period: int | None = None, stream=None):
+        """CLOUDSC2_ARRAY_STATE_VALIDATE (cloudsc2_array_state_mod.F90:205-258) on the device, against the KLON-column
+        reference table ``ref`` (dataset names of reference.h5), never expanded.  Returns [(name, ndim, stats[5])] in
+        the reference's print order and the report text (header + one ERROR_PRINT line per variable)."""
+        torch = self.torch
+        S, H = self.nproma * self.nlev, self.nproma * (self.nlev + 1)
+        ws = torch.empty(B.lib.cloudsc2_validate_workspace_doubles(), dtype=torch.float64, device=self.device)
+        dp = lambda t: C.cast(t.data_ptr(), C.POINTER(C.c_double))  # noqa: E731
+        plan = [("PLUDE", self.PLUDE, 0, S, 1), ("PCOVPTOT", self.PCOVPTOT, 0, S, 1), ("PFPLSL", self.PFPLSL, 0, H, 1),
+                ("PFPLSN", self.PFPLSN, 0, H, 1), ("PFHPSL", self.PFHPSL, 0, H, 1), ("PFHPSN", self.PFHPSN, 0, H, 1),
+                ("TENDENCY_LOC_A", self.B_LOC, PLANE_A * S, 8 * S, 1), ("TENDENCY_LOC_Q", self.B_LOC, PLANE_Q * S, 8 * S, 1),
+                ("TENDENCY_LOC_T", self.B_LOC, PLANE_T * S, 8 * S, 1), ("TENDENCY_LOC_CLD", self.B_LOC, PLANE_QL * S, 8 * S, 5)]
+        labels = {"TENDENCY_LOC_A": "TENDENCY_LOC%A", "TENDENCY_LOC_Q": "TENDENCY_LOC%Q", "TENDENCY_LOC_T": "TENDENCY_LOC%T",
+                  "TENDENCY_LOC_CLD": "TENDENCY_LOC%CLD"}
+        rows, keep = [], []
+        for name, fld, off, stride, ndim in plan:
+            tabdev = torch.from_numpy(np.ascontiguousarray(ref[name], dtype=np.float64)).to(self.device)
+            keep.append(tabdev)
+            klon = tabdev.shape[-1]
+            nlevx = tabdev.shape[-2]
+            stats = torch.empty(5, dtype=torch.float64, device=self.device)
+            B.check(B.lib.cloudsc2_validate_launch(dp(tabdev), klon, klon if period is None else period, start, nlevx, ndim,
+                                                   self.nproma, self.ngptot, _fld(fld, off, stride), dp(ws), dp(stats),
+                                                   self._stream(stream)))
+            rows.append((labels.get(name, name), 2 if ndim == 1 else 3, stats))
+        torch.cuda.synchronize(self.device)
+        rows = [(n, d, s.cpu().numpy()) for n, d, s in rows]
+        nglob = self.ngptot if ngptotg is None else ngptotg
+        text = "\n".join([B.validate_header()] + [B.validate_line(n, d, s, nglob) for n, d, s in rows])
+        return rows, text
 
     # -- argument blocks in the driver-array -> kernel-dummy mapping of cloudsc_driver_mod.F90:94-107 --
     def traj_inputs(self, with_qsat: bool = False) -> B.Inputs:

@@ -182,6 +182,41 @@ void cloudsc2_release_workspace(void);
 int cloudsc2_taylor_verdict(const double znormg[10], int* itest);
 int cloudsc2_adjoint_verdict(double znormg);
 
+/* --------------------------------------------------------------------------------------------------
+ * Data formats either side of the path, device side.  The HDF5 files hold
+ * KLON-column tables, stored (…, KLON) in C order = Fortran (KLON, …) (hdf5_file_mod.F90); the file
+ * reader/writer itself is include/cloudsc2_io.h (libcloudsc2_io.so, needs libhdf5).
+ *
+ * cloudsc2_expand_launch  replaces EXPAND_R2/R3 (src/common/module/expand_mod.F90:270-335) for data that
+ *   stays on the GPU: field(jl,jk,jm,ibl) = table((start + ibl*NPROMA + jl) mod period, jk, jm), zero in the
+ *   padded tail of the last block.  `table` (device) is (KLON, nlevx, ndim) column-fastest; `period` and
+ *   `start` are GET_OFFSETS' size and start-1 (expand_mod.F90:30-46; see cloudsc2_expand_offsets).  The
+ *   reference indexes out of bounds when a block starts at a multiple of KLON other than KLON itself
+ *   (MOD(gidx,nlon) = 0, :289); this implements the periodic tiling it intends.
+ * cloudsc2_validate_launch  replaces VALIDATE_R2/R3 (src/common/module/validate_mod.F90:165-261) without
+ *   expanding the reference: stats[5] (device) = { min FIELD, max FIELD (whole blocks, padding included),
+ *   max |FIELD-REF|, sum |FIELD-REF|, sum |REF| (active columns) }.  `workspace` (device) needs
+ *   cloudsc2_validate_workspace_doubles() doubles.  Sums are folded in a fixed order (deterministic).
+ * ------------------------------------------------------------------------------------------------ */
+int cloudsc2_expand_launch(const double* table, int klon, int period, long long start, int nlevx, int ndim,
+                           int nproma, long long ngptot, cloudsc2_field field, void* stream);
+int cloudsc2_validate_workspace_doubles(void);
+int cloudsc2_validate_launch(const double* table, int klon, int period, long long start, int nlevx, int ndim,
+                             int nproma, long long ngptot, cloudsc2_field field, double* workspace,
+                             double* stats, void* stream);
+/* GET_OFFSETS (expand_mod.F90:30-46): which table columns rank `irank` of `numproc` tiles from.
+ * ngptotg <= 0 means "not given".  *start is 0-based. */
+void cloudsc2_expand_offsets(int klon, long long ngptot, long long ngptotg, int irank, int numproc,
+                             long long* start, int* period);
+/* ERROR_PRINT (validate_mod.F90:263-296): relative error in percent, option code 1..3, and whether the
+ * line carries the "!!!!" warning (relative error > 10 eps).  Pure host code.  zavgpgp = esum / ngptotg. */
+double cloudsc2_validate_relerr(double esum, double rsum, int* iopt, int* warn);
+/* The line ERROR_PRINT writes, FORMAT(1X,A20,1X,I1,'D',I1,5(1X,E20.13),A); buf needs >= 160 bytes. */
+int cloudsc2_validate_format(const char* name, int ndim, const double stats[5], long long ngptotg,
+                             char* buf, int buflen);
+/* The header line CLOUDSC2_ARRAY_STATE_VALIDATE prints first (cloudsc2_array_state_mod.F90:226-229). */
+int cloudsc2_validate_header(char* buf, int buflen);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,18 @@ def test_every_declared_symbol_is_exported():
         assert hasattr(B.lib, s), s
 
 
+def test_io_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "cloudsc2_io.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    syms = sorted(set(re.findall(r"\b(cloudsc2_[a-z0-9_]+)\s*\(", hdr)))
+    assert "cloudsc2_file_open" in syms and "cloudsc2_file_read_params" in syms
+    from dwarf_p_cloudsc2_tl_ad_amd import fileio
+
+    lib = fileio._lib()
+    for s in syms:
+        assert hasattr(lib, s), s
+
+
 def test_params_struct_layout_and_defaults():
     assert C.sizeof(B.Params) == 30 * 8 + 6 * 4 + 200 * 8
     p = c2.default_params()

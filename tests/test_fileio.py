@@ -1,0 +1,122 @@
+"""input.h5 / reference.h5 reader-writer (libcloudsc2_io.so), GET_OFFSETS and the validator's report format -- all host
+code, no GPU.  Reference behaviour: cloudsc2_array_state_mod.F90:153-287, expand_mod.F90:30-46, validate_mod.F90:263-296."""
+from __future__ import annotations
+
+import math
+import os
+
+import numpy as np
+import pytest
+
+from tests.util import ROOT, B, c2
+from dwarf_p_cloudsc2_tl_ad_amd import fileio
+
+REF_H5 = "/root/reference/config-files/reference.h5"
+
+
+def test_input_file_round_trip(tmp_path):
+    tab = c2.random_table(137, 100, seed=5)
+    prm = c2.default_params(c2.ceta_from_table(tab))
+    prm.nlev = 137
+    path = str(tmp_path / "input.h5")
+    fileio.write_input_file(path, tab, prm)
+    with fileio.H5File(path) as f:
+        # the layout the reference's loader expects (cloudsc2_array_state_mod.F90:159-199)
+        assert f.shape("PT") == (137, 100) and f.shape("PAPH") == (138, 100) and f.shape("PCLV") == (5, 137, 100)
+        assert f.shape("TENDENCY_CML_CLD") == (5, 137, 100) and f.shape("KLON") == (1,) and f.scalar("KLON", np.int32) == 100
+        assert f.has("YRECLDP_RCLCRIT") and f.has("YREPHLI_RLPTRC") and not f.has("NOPE")
+        with pytest.raises(fileio.IOError_):
+            f.read("NOPE")
+    got, p2 = fileio.read_input_file(path)
+    for k, v in tab.items():
+        assert np.array_equal(np.asarray(v), np.asarray(got[k])), k
+    for name, _ in B.Params._fields_:
+        if name in ("ceta", "reserved", "lregcl", "ldrain1d"):
+            continue
+        assert getattr(p2, name) == getattr(prm, name), name
+    assert np.array_equal(np.array(p2.ceta[:137]), c2.ceta_from_table(tab))  # dwarf_cloudsc.F90:100-102
+    assert p2.lphylin == 1 and p2.levapls2 == 0 and p2.rvtmp2 == 0.0
+    _, p3 = fileio.read_input_file(path, lregcl=True)
+    assert p3.lregcl == 1
+    # the state built from the file equals the state built from the table
+    a, b = c2.state_from_table(tab, 32, 250), c2.state_from_table(got, 32, 250)
+    for n in a.DRIVER_ORDER:
+        assert np.array_equal(getattr(a, n), getattr(b, n)), n
+
+
+@pytest.mark.skipif(not os.path.exists(REF_H5), reason="reference checkout not present")
+def test_reads_the_reference_h5_of_the_checkout():
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "reference_h5.npz"))
+    ref = fileio.read_reference_file(REF_H5)
+    for n in fileio.REFERENCE_FIELDS:
+        assert np.array_equal(ref[n], gold[n]), n
+    with fileio.H5File(REF_H5) as f:
+        assert f.scalar("KLON", np.int32) == 100 and f.scalar("KLEV", np.int32) == 137
+
+
+def test_reference_file_round_trip(tmp_path):
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "reference_h5.npz"))
+    path = str(tmp_path / "reference.h5")
+    fileio.write_reference_file(path, {n: gold[n] for n in fileio.REFERENCE_FIELDS})
+    back = fileio.read_reference_file(path)
+    for n in fileio.REFERENCE_FIELDS:
+        assert back[n].shape == gold[n].shape and np.array_equal(back[n], gold[n]), n
+    # WRITE_REFERENCE takes block 1 of an NPROMA=100 state (:265-284): same thing from any blocking
+    tab = c2.synthetic_table()
+    st = c2.state_from_table(tab, 32, 250)
+    st.PCOVPTOT[:] = np.arange(st.PCOVPTOT.size, dtype=np.float64).reshape(st.PCOVPTOT.shape)
+    st.B_LOC[:] = np.arange(st.B_LOC.size, dtype=np.float64).reshape(st.B_LOC.shape)
+    ref = fileio.reference_table_from_state(st, 100)
+    cols = st.PCOVPTOT.transpose(0, 2, 1).reshape(-1, 137)[:100]
+    assert np.array_equal(ref["PCOVPTOT"], cols.T) and ref["TENDENCY_LOC_CLD"].shape == (5, 137, 100)
+    assert np.array_equal(ref["TENDENCY_LOC_CLD"][1], st.B_LOC[:, 4].transpose(0, 2, 1).reshape(-1, 137)[:100].T)
+
+
+def test_expand_offsets_follow_get_offsets():
+    def get_offsets(nlon, ngptot, ngptotg, irank, numproc):  # expand_mod.F90:30-46, 0-based start
+        use_offset = ngptotg is not None and nlon >= ngptotg
+        start = irank * ((ngptotg - 1) // numproc + 1) if use_offset else 0
+        return start, min(nlon, ngptot)
+
+    for nlon, ngptot, ngptotg, irank, numproc in [(100, 160000, 160000, 0, 1), (100, 20000, 160000, 3, 8), (100, 25, 100, 2, 4),
+                                                   (100, 25, 100, 3, 4), (100, 64, None, 0, 1), (100, 13, 50, 1, 4)]:
+        got = c2.binding.expand_offsets(nlon, ngptot, 0 if ngptotg is None else ngptotg, irank, numproc)
+        assert got == get_offsets(nlon, ngptot, ngptotg, irank, numproc), (nlon, ngptot, ngptotg, irank, numproc)
+
+
+def fortran_e20_13(v: float) -> str:
+    """Independent restatement of the E20.13 edit descriptor."""
+    if v == 0.0:
+        body = "0.0000000000000E+00"
+    else:
+        ex = math.floor(math.log10(abs(v))) + 1
+        mant = abs(v) / 10.0**ex
+        digits = f"{mant:.13f}"
+        if digits.startswith("1."):  # rounding carried into the units digit
+            ex += 1
+            digits = f"{abs(v) / 10.0**ex:.13f}"
+        body = ("-" if v < 0 else "") + digits + (f"E{ex:+03d}" if abs(ex) < 100 else f"{ex:+04d}")
+    return body.rjust(20)
+
+
+def test_validator_report_format():
+    assert c2.binding.validate_header() == " " + "Variable".rjust(20) + " Dim" + "".join(
+        " " + s.rjust(20) for s in ("MinValue", "MaxValue", "AbsMaxErr", "AvgAbsErr/GP", "MaxRelErr-%"))
+    # ERROR_PRINT (validate_mod.F90:263-296): option codes, the 10*eps warning rule, FORMAT(1X,A20,1X,I1,'D',I1,5(1X,E20.13),A)
+    eps = np.finfo(np.float64).eps
+    cases = [
+        ("PCOVPTOT", 2, [0.0, 1.0, 0.0, 0.0, 5.0e3], 100, 1, False, 0.0),
+        ("PFPLSL", 2, [0.0, 3.9e-4, 1e-12, 4e-10, 1e-20], 100, 2, True, 100 * 4e-10 / (1.0 + 1e-20)),
+        ("TENDENCY_LOC%CLD", 3, [-2.5e-7, 3.0e-7, 1e-22, 3e-16, 2.0], 160000, 3, False, 100 * 3e-16 / 2.0),
+        ("PFHPSN", 2, [-1.2345678901234567e3, 0.0, 2.5e-9, 1e-6, 1e5], 100, 3, True, 100 * 1e-6 / 1e5),
+    ]
+    for name, ndim, stats, n, iopt, warn, rel in cases:
+        line = c2.binding.validate_line(name, ndim, stats, n)
+        want = " " + name.rjust(20) + f" {ndim}D{iopt}" + "".join(
+            " " + fortran_e20_13(x) for x in (stats[0], stats[1], stats[2], stats[3] / n, rel)) + (" !!!!" if warn else "     ")
+        assert line == want, (line, want)
+        assert (rel / 100 > 10 * eps) == warn
+    assert fortran_e20_13(1.0) == " 0.1000000000000E+01" and fortran_e20_13(-0.5) == "-0.5000000000000E+00"
+    line = c2.binding.validate_line("X", 2, [9.9999999999999995e-8, 1e300, 1e-300, 0, 0], 1)
+    assert line[25:46] == "  0.1000000000000E-06"      # rounding carries into the exponent
+    assert line[46:67] == "  0.1000000000000+301" and line[67:88] == "  0.1000000000000-299"  # three-digit exponents drop the E

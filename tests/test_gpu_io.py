@@ -1,0 +1,118 @@
+"""Device-side data-format kernels (include/cloudsc2_hip.h: cloudsc2_expand_launch, cloudsc2_validate_launch) against
+host restatements of EXPAND_R2/R3 (expand_mod.F90:270-335) and VALIDATE_R2/R3 (validate_mod.F90:165-261), and the
+file -> device state -> NL -> validation-report chain of the reference's main (dwarf_cloudsc.F90:79-124)."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from tests.util import B, c2
+from dwarf_p_cloudsc2_tl_ad_amd import fileio
+
+pytestmark = pytest.mark.gpu
+
+
+def host_validate(field, ref_tab, nproma, ngptot, start=0, period=None):
+    """VALIDATE_R2 / R3 in numpy: field (NBLOCKS, [NDIM,] NLEVx, NPROMA), ref_tab ([NDIM,] NLEVx, KLON)."""
+    klon = ref_tab.shape[-1]
+    period = klon if period is None else period
+    cols = (start + np.arange(ngptot)) % period
+    nlevx = field.shape[-2]
+    if field.ndim == 3:
+        f = field.transpose(0, 2, 1).reshape(-1, nlevx)[:ngptot]           # (col, lev)
+        r = ref_tab.T[cols]
+    else:
+        ndim = field.shape[1]
+        f = field.transpose(0, 3, 1, 2).reshape(-1, ndim, nlevx)[:ngptot]  # (col, dim, lev)
+        r = ref_tab.transpose(2, 0, 1)[cols]
+    d = np.abs(f - r)
+    return np.array([field.min(), field.max(), d.max(), d.sum(), np.abs(r).sum()])
+
+
+@pytest.mark.parametrize("nproma,ngptot,start,period", [(32, 250, 0, None), (100, 100, 0, None), (128, 1000, 37, None),
+                                                        (64, 70, 25, 25), (1, 7, 0, 7)])
+def test_device_expand_equals_host_tiling(nproma, ngptot, start, period):
+    import torch
+
+    tab = c2.random_table(137, 100, seed=11)
+    host = c2.state_from_table(tab, nproma, ngptot, col0=start) if period is None else None
+    ds = c2.DeviceState.from_table(tab, nproma, ngptot, start=start, period=period)
+    torch.cuda.synchronize()
+    if host is not None:
+        for n in ("PT", "PQ", "PAP", "PAPH", "PLU", "PLUDE", "PMFU", "PMFD", "PA", "PSUPSAT", "B_CML", "PCLV"):
+            assert np.array_equal(getattr(ds, n).cpu().numpy(), getattr(host, n)), n
+        for n in ("PCOVPTOT", "PFPLSL", "PFPLSN", "PFHPSL", "PFHPSN", "B_LOC"):
+            assert not getattr(ds, n).any(), n
+    else:
+        # a rank whose table slice is shorter than KLON (GET_OFFSETS: size = min(nlon, ngptot), start = rank offset)
+        cols = ds.PT.cpu().numpy().transpose(0, 2, 1).reshape(-1, 137)
+        idx = (start + np.arange(ngptot)) % period
+        assert np.array_equal(cols[:ngptot], tab["PT"].T[idx]) and not cols[ngptot:].any()
+
+
+def test_expand_and_validate_reject_bad_arguments():
+    import ctypes as C
+
+    import torch
+
+    t = torch.zeros(137 * 100, dtype=torch.float64, device="cuda:0")
+    f = torch.zeros(4 * 137 * 32, dtype=torch.float64, device="cuda:0")
+    dp = lambda x: C.cast(x.data_ptr(), C.POINTER(C.c_double))  # noqa: E731
+    fld = B.Field(f.data_ptr(), 137 * 32)
+    ok = (dp(t), 100, 100, 0, 137, 1, 32, 100, fld, None)
+    assert B.lib.cloudsc2_expand_launch(*ok) == 0
+    for i, bad in ((2, 101), (2, 0), (3, -1), (6, 0), (7, 0)):
+        args = list(ok)
+        args[i] = bad
+        assert B.lib.cloudsc2_expand_launch(*args) == B.CLOUDSC2_EINVAL, (i, bad)
+    small = B.Field(f.data_ptr(), 137 * 32 - 1)
+    assert B.lib.cloudsc2_expand_launch(*ok[:8], small, None) == B.CLOUDSC2_EINVAL
+    torch.cuda.synchronize()
+
+
+def test_validator_statistics_match_the_host_restatement(tmp_path):
+    """input file -> device state -> NL -> reference file -> validation, at a size with a ragged tail."""
+    import torch
+
+    tab = c2.synthetic_table()
+    prm0 = c2.default_params(c2.ceta_from_table(tab))
+    prm0.nlev = 137
+    fileio.write_input_file(str(tmp_path / "input.h5"), tab, prm0)
+    tab2, prm = fileio.read_input_file(str(tmp_path / "input.h5"))
+    nproma, ngptot = 128, 16300
+    ds = c2.DeviceState.from_table(tab2, nproma, ngptot)
+    ds.nl(prm)
+    torch.cuda.synchronize()
+    st = ds.download(c2.state_from_table(tab, nproma, ngptot))
+    # reference.h5 written from the first 100 columns (WRITE_REFERENCE), read back, validated: the tiling is periodic and
+    # the kernels are deterministic, so every error is exactly zero (option code 1) and no line carries "!!!!"
+    ref = fileio.reference_table_from_state(st, 100)
+    fileio.write_reference_file(str(tmp_path / "reference.h5"), ref)
+    ref = fileio.read_reference_file(str(tmp_path / "reference.h5"))
+    rows, text = ds.validate(ref)
+    lines = text.split("\n")
+    assert lines[0] == B.validate_header() and len(lines) == 11
+    names = [r[0] for r in rows]
+    assert names == ["PLUDE", "PCOVPTOT", "PFPLSL", "PFPLSN", "PFHPSL", "PFHPSN", "TENDENCY_LOC%A", "TENDENCY_LOC%Q",
+                     "TENDENCY_LOC%T", "TENDENCY_LOC%CLD"]  # print order of cloudsc2_array_state_mod.F90:246-256
+    for (name, ndim, s), line in zip(rows, lines[1:]):
+        assert s[2] == 0.0 and s[3] == 0.0, (name, s)
+        assert line.startswith(" " + name.rjust(20) + f" {ndim}D1") and "!!!!" not in line
+    # statistics against numpy (VALIDATE_R2/R3) with a reference that differs
+    rng = np.random.default_rng(3)
+    ref2 = {k: v * (1.0 + 1e-9 * rng.standard_normal(v.shape)) for k, v in ref.items()}
+    rows2, text2 = ds.validate(ref2, ngptotg=2 * ngptot)
+    fields = {"PLUDE": st.PLUDE, "PCOVPTOT": st.PCOVPTOT, "PFPLSL": st.PFPLSL, "PFPLSN": st.PFPLSN, "PFHPSL": st.PFHPSL,
+              "PFHPSN": st.PFHPSN, "TENDENCY_LOC%A": st.B_LOC[:, 1], "TENDENCY_LOC%Q": st.B_LOC[:, 2],
+              "TENDENCY_LOC%T": st.B_LOC[:, 0], "TENDENCY_LOC%CLD": st.B_LOC[:, 3:8]}
+    keys = dict(zip(fields, ref2))
+    for (name, ndim, s), line in zip(rows2, text2.split("\n")[1:]):
+        want = host_validate(fields[name], ref2[keys[name]], nproma, ngptot)
+        assert s[0] == want[0] and s[1] == want[1] and s[2] == want[2], (name, s, want)
+        assert np.allclose(s[3:], want[3:], rtol=1e-12, atol=0), (name, s, want)
+        assert line == B.validate_line(name, ndim, s, 2 * ngptot)
+    assert "!!!!" in text2
+    # a second validation of the same data gives the same bits (fixed-order reduction)
+    rows3, _ = ds.validate(ref2, ngptotg=2 * ngptot)
+    for a, b in zip(rows2, rows3):
+        assert np.array_equal(a[2], b[2])
