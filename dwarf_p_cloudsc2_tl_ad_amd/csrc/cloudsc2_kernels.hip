@@ -758,8 +758,9 @@ static void fortran_e20_13(double v, char out[24]) {
   digits[13] = 0;
   if (v != 0.0) ex += 1;
   char body[32];
-  if (ex > 99 || ex < -99) snprintf(body, sizeof body, "%s0.%s%c%03d", v < 0 ? "-" : "", digits, ex < 0 ? '-' : '+', abs(ex));
-  else snprintf(body, sizeof body, "%s0.%sE%c%02d", v < 0 ? "-" : "", digits, ex < 0 ? '-' : '+', abs(ex));
+  const char* sign = std::signbit(v) ? "-" : "";  // Fortran prints the sign of a negative zero too
+  if (ex > 99 || ex < -99) snprintf(body, sizeof body, "%s0.%s%c%03d", sign, digits, ex < 0 ? '-' : '+', abs(ex));
+  else snprintf(body, sizeof body, "%s0.%sE%c%02d", sign, digits, ex < 0 ? '-' : '+', abs(ex));
   snprintf(out, 24, "%20s", body);
 }
 

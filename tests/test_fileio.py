@@ -87,7 +87,7 @@ def test_expand_offsets_follow_get_offsets():
 def fortran_e20_13(v: float) -> str:
     """Independent restatement of the E20.13 edit descriptor."""
     if v == 0.0:
-        body = "0.0000000000000E+00"
+        body = ("-" if math.copysign(1.0, v) < 0 else "") + "0.0000000000000E+00"
     else:
         ex = math.floor(math.log10(abs(v))) + 1
         mant = abs(v) / 10.0**ex
@@ -117,6 +117,7 @@ def test_validator_report_format():
         assert line == want, (line, want)
         assert (rel / 100 > 10 * eps) == warn
     assert fortran_e20_13(1.0) == " 0.1000000000000E+01" and fortran_e20_13(-0.5) == "-0.5000000000000E+00"
+    assert c2.binding.validate_line("X", 2, [-0.0, 0.0, 0, 0, 0], 1)[25:67] == " -0.0000000000000E+00  0.0000000000000E+00"
     line = c2.binding.validate_line("X", 2, [9.9999999999999995e-8, 1e300, 1e-300, 0, 0], 1)
     assert line[25:46] == "  0.1000000000000E-06"      # rounding carries into the exponent
     assert line[46:67] == "  0.1000000000000+301" and line[67:88] == "  0.1000000000000-299"  # three-digit exponents drop the E

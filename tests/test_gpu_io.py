@@ -116,3 +116,91 @@ def test_validator_statistics_match_the_host_restatement(tmp_path):
     rows3, _ = ds.validate(ref2, ngptotg=2 * ngptot)
     for a, b in zip(rows2, rows3):
         assert np.array_equal(a[2], b[2])
+
+
+def golden_reference_table(tab):
+    """What reference.h5 would hold for the synthetic input: the unmodified reference Fortran's outputs on the 100
+    synthetic columns (tests/golden/nl_synth100.npz, generated by tests/golden/make_golden.py)."""
+    import os
+
+    from tests.util import ROOT
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "nl_synth100.npz"))
+    z = np.zeros_like(g["out_tent"])
+    return {"PLUDE": tab["PLUDE"], "PCOVPTOT": g["out_covptot"], "PFPLSL": g["out_fplsl"], "PFPLSN": g["out_fplsn"],
+            "PFHPSL": g["out_fhpsl"], "PFHPSN": g["out_fhpsn"], "TENDENCY_LOC_A": z, "TENDENCY_LOC_Q": g["out_tenq"],
+            "TENDENCY_LOC_T": g["out_tent"], "TENDENCY_LOC_CLD": np.stack([g["out_tenl"], g["out_teni"], z, z, z])}
+
+
+def test_gpu_results_pass_the_references_own_validation():
+    """VALIDATE's criterion (validate_mod.F90:286: L1 relative error <= 10 eps per variable, else "!!!!") against the
+    reference Fortran's outputs, in both math modes."""
+    tab = c2.synthetic_table()
+    prm = c2.default_params(c2.ceta_from_table(tab))
+    ref = golden_reference_table(tab)
+    try:
+        for precise in (False, True):
+            c2.set_math_mode(precise)
+            ds = c2.DeviceState.from_table(tab, 128, 16384)
+            ds.nl(prm)
+            rows, text = ds.validate(ref)
+            assert "!!!!" not in text, text
+            for name, _, s in rows:
+                rel = s[3] / s[4] if s[4] > 0 else s[3]
+                assert rel <= 10 * np.finfo(np.float64).eps, (precise, name, rel)
+    finally:
+        c2.set_math_mode(False)
+
+
+def test_fortran_main_loads_validates_and_writes_reference(tmp_path):
+    """dwarf-cloudsc2-nl with the flow of the reference's main (dwarf_cloudsc.F90:79-124): GLOBAL_STATE%LOAD from input.h5,
+    CLOUDSC_DRIVER, GLOBAL_STATE%VALIDATE against reference.h5 in the reference's table format, WRITE_REFERENCE."""
+    import os
+
+    import torch
+
+    from tests.test_gpu_parity import _run_fortran
+
+    tab = c2.synthetic_table()
+    prm = c2.default_params(c2.ceta_from_table(tab))
+    prm.nlev = 137
+    ref = golden_reference_table(tab)
+    run = tmp_path / "run"
+    run.mkdir()
+    fileio.write_input_file(str(run / "input.h5"), tab, prm)
+    fileio.write_reference_file(str(run / "reference.h5"), ref)
+    nproma, ngptot = 128, 16300
+    out, _ = _run_fortran("dwarf-cloudsc2-nl", 1, ngptot, nproma, cwd=str(run))
+    lines = [ln for ln in out.split("\n") if ln.strip()]
+    i0 = next(i for i, ln in enumerate(lines) if ln == B.validate_header())
+    table = lines[i0 + 1:i0 + 11]
+    # the same validation on the device through the Python driver
+    ds = c2.DeviceState.from_table(tab, nproma, ngptot)
+    ds.nl(prm)
+    rows, text = ds.validate(ref)
+    assert "!!!!" not in out
+    for got, want, (name, ndim, s) in zip(table, text.split("\n")[1:], rows):
+        assert got[:25] == want[:25], (got, want)                      # name, rank, option code
+        g = [float(x) for x in got[25:130].split()]
+        w = [float(x) for x in want[25:130].split()]
+        assert g[:3] == w[:3], (got, want)  # min, max, max abs error: the same doubles (a zero may differ in sign)
+        assert np.allclose(g[3:], w[3:], rtol=1e-9, atol=1e-300), (got, want)  # the sums: sequential vs tree order
+    # WRITE_REFERENCE: any NPROMA (the reference insists on 100), equal to the table taken from the Python driver's state
+    wr = tmp_path / "write"
+    wr.mkdir()
+    fileio.write_input_file(str(wr / "input.h5"), tab, prm)
+    out, _ = _run_fortran("dwarf-cloudsc2-nl", 1, 300, 64, cwd=str(wr), env={"CLOUDSC2_WRITE_REFERENCE": "1"})
+    assert os.path.exists(wr / "reference.h5")
+    back = fileio.read_reference_file(str(wr / "reference.h5"))
+    st = c2.state_from_table(tab, 64, 300)
+    c2.run_state(prm, st, "nl")
+    mine = fileio.reference_table_from_state(st, 100)
+    for n in fileio.REFERENCE_FIELDS:
+        assert np.array_equal(back[n], mine[n]), n
+    # and a run validated against the file it has just written reports exact agreement
+    out, _ = _run_fortran("dwarf-cloudsc2-nl", 1, 1000, 32, cwd=str(wr))
+    import re
+
+    lines = [ln for ln in out.split("\n") if re.fullmatch(r"\dD\d", ln[22:25])]
+    assert len(lines) == 10 and all(ln[22:25] in ("2D1", "3D1") for ln in lines), out
+    torch.cuda.synchronize()

@@ -303,7 +303,7 @@ def test_invalid_arguments_fail_loudly():
         c2.run_state(prm, st, "nl")
 
 
-def _run_fortran(exe, *args):
+def _run_fortran(exe, *args, cwd=None, env=None):
     import os
     import subprocess
 
@@ -312,7 +312,8 @@ def _run_fortran(exe, *args):
     path = os.path.join(ROOT, "dwarf_p_cloudsc2_tl_ad_amd", "fortran", "build", exe)
     if not os.path.exists(path):
         pytest.fail(f"{path} missing: run __graft_entry__.build()")
-    r = subprocess.run([path, *map(str, args)], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([path, *map(str, args)], capture_output=True, text=True, timeout=300, cwd=cwd,
+                       env=None if env is None else {**os.environ, **env})
     assert r.returncode == 0, r.stdout + r.stderr
     return r.stdout, r.stderr
 
