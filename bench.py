@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--nproma", type=int, default=128)
     ap.add_argument("--kernel", choices=["nl", "tl", "ad"], default="nl")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--levapls2", action="store_true", help="switch the evaporation branch on (off in every shipped config)")
     args = ap.parse_args()
 
     import torch
@@ -109,7 +110,7 @@ def main():
     dev = torch.device("cuda", local)
 
     tab = c2.synthetic_table()
-    prm = c2.default_params(c2.ceta_from_table(tab), lregcl=(args.kernel == "ad"))
+    prm = c2.default_params(c2.ceta_from_table(tab), lregcl=(args.kernel == "ad"), levapls2=args.levapls2)
     col0 = rank * args.ngptot  # weak scaling: rank r owns global columns [r*NGPTOT, (r+1)*NGPTOT)
     # the state is tiled on the device from the 100-column table (cloudsc2_expand_launch): no host copy of it exists
     ds = c2.DeviceState.from_table(tab, args.nproma, args.ngptot, dev, start=col0)
