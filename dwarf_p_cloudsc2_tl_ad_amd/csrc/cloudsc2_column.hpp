@@ -93,26 +93,49 @@ struct RawLevel {
   real_t paph_k1, pap, q, qsat, t, l, i, lude, lu_k1, mfu, mfd, gt, gq, gl, gi, supsat;
 };
 
+// Streaming accesses: every plane element is read once and written once per launch.  C2_NT_LOAD / C2_NT_STORE = 1
+// mark them non-temporal (`nt`), so they do not displace the little that is re-read (tropopause band, level tables).
+#ifndef C2_NT_LOAD
+#define C2_NT_LOAD 1
+#endif
+#ifndef C2_NT_STORE
+#define C2_NT_STORE 1
+#endif
+C2_HD real_t ldg(const double* p, long long i) {
+#if C2_NT_LOAD && defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_nontemporal_load(p + i);
+#else
+  return p[i];
+#endif
+}
+C2_HD void stg(double* p, long long i, real_t v) {
+#if C2_NT_STORE && defined(__HIP_DEVICE_COMPILE__)
+  __builtin_nontemporal_store(v, p + i);
+#else
+  p[i] = v;
+#endif
+}
+
 template <bool HAS_QSAT>
 C2_HD void load_level(InPtrsP pp, const LaneOff& o, int nproma, int nlev, int jk, RawLevel& r) {
   const InPtrs p = *pp;
   const long long d = (long long)jk * nproma;
-  r.paph_k1 = p.paph[o.half + d + nproma];
-  r.lu_k1 = (jk + 1 < nlev) ? p.lu[o.full + d + nproma] : 0.0;
-  r.pap = p.pap[o.full + d];
-  r.q = p.q[o.full + d];
-  r.t = p.t[o.full + d];
-  r.l = p.l[o.clv + d];
-  r.i = p.i[o.clv + d];
-  r.lude = p.lude[o.full + d];
-  r.mfu = p.mfu[o.full + d];
-  r.mfd = p.mfd[o.full + d];
-  r.gt = p.gt[o.cml + d];
-  r.gq = p.gq[o.cml + d];
-  r.gl = p.gl[o.cml + d];
-  r.gi = p.gi[o.cml + d];
-  r.supsat = p.supsat[o.full + d];
-  if (HAS_QSAT) r.qsat = p.qsat[o.full + d];
+  r.paph_k1 = ldg(p.paph, o.half + d + nproma);
+  r.lu_k1 = (jk + 1 < nlev) ? ldg(p.lu, o.full + d + nproma) : 0.0;
+  r.pap = ldg(p.pap, o.full + d);
+  r.q = ldg(p.q, o.full + d);
+  r.t = ldg(p.t, o.full + d);
+  r.l = ldg(p.l, o.clv + d);
+  r.i = ldg(p.i, o.clv + d);
+  r.lude = ldg(p.lude, o.full + d);
+  r.mfu = ldg(p.mfu, o.full + d);
+  r.mfd = ldg(p.mfd, o.full + d);
+  r.gt = ldg(p.gt, o.cml + d);
+  r.gq = ldg(p.gq, o.cml + d);
+  r.gl = ldg(p.gl, o.cml + d);
+  r.gi = ldg(p.gi, o.cml + d);
+  r.supsat = ldg(p.supsat, o.full + d);
+  if (HAS_QSAT) r.qsat = ldg(p.qsat, o.full + d);
 }
 
 // Perturbed state of the Taylor test: x5 = x + lambda*(0.01*x) (cloudsc_driver_tl_mod.F90:156-171,200-215).
@@ -183,17 +206,17 @@ C2_HD real_t tropopause(ConstsP c, LevelTabP tab, InPtrsP p, const LaneOff& o, G
 C2_HD void store_out(OutPtrsP pp, const LaneOff& o, int nproma, int jk, const LevelOut& v) {
   const OutPtrs p = *pp;
   const long long d = (long long)jk * nproma;
-  p.tent[o.loc + d] = v.tent;
-  p.tenq[o.loc + d] = v.tenq;
-  p.tenl[o.loc + d] = v.tenl;
-  p.teni[o.loc + d] = v.teni;
-  p.clc[o.full + d] = v.clc;
-  p.covptot[o.full + d] = v.covptot;
+  stg(p.tent, o.loc + d, v.tent);
+  stg(p.tenq, o.loc + d, v.tenq);
+  stg(p.tenl, o.loc + d, v.tenl);
+  stg(p.teni, o.loc + d, v.teni);
+  stg(p.clc, o.full + d, v.clc);
+  stg(p.covptot, o.full + d, v.covptot);
   const long long d1 = d + nproma;
-  p.fplsl[o.half + d1] = v.fplsl;
-  p.fplsn[o.half + d1] = v.fplsn;
-  p.fhpsl[o.half + d1] = v.fhpsl;
-  p.fhpsn[o.half + d1] = v.fhpsn;
+  stg(p.fplsl, o.half + d1, v.fplsl);
+  stg(p.fplsn, o.half + d1, v.fplsn);
+  stg(p.fhpsl, o.half + d1, v.fhpsl);
+  stg(p.fhpsn, o.half + d1, v.fhpsn);
 }
 
 C2_HD void store_top(OutPtrsP p, const LaneOff& o, ConstsP c) {
@@ -241,7 +264,7 @@ C2_HD void satur_column(long long gcol, SaturArgsP a) {
   double* qsat = a->qsat;
   for (int jk = 0; jk < nlev; ++jk) {
     long long d = (long long)jk * nproma;
-    qsat[o.full + d] = satur_point<P>(C2_CONSTS(a), pap[o.full + d], t[o.full + d]);
+    stg(qsat, o.full + d, satur_point<P>(C2_CONSTS(a), ldg(pap, o.full + d), ldg(t, o.full + d)));
   }
 }
 
@@ -317,14 +340,14 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
     level_cst(tab, jk, last, k);
     LevelIn x;
     make_level_in(cur, paph_k, paph_surf, x);
-    if (CKPT) ckpt[osc + (long long)jk * nproma] = cy.covptot;  // ZCOVPTOT5(JK-1)
+    if (CKPT) stg(ckpt, osc + (long long)jk * nproma, cy.covptot);  // ZCOVPTOT5(JK-1)
     LevelTraj tr;
     LevelOut lo;
     level_forward<P, EVAP>(c, k, rh, x, cy, tr, lo);
     C2_LAUNDER(ap);
     out = &ap->out;
     store_out(out, o, nproma, jk, lo);
-    if (zero_plane) zero_plane[ozero + (long long)jk * nproma] = 0.0;
+    if (zero_plane) stg(zero_plane, ozero + (long long)jk * nproma, 0.0);
     paph_k = cur.paph_k1;
     cur = nxt;
   }
@@ -439,56 +462,56 @@ C2_HD void ad_load_level(AdArgsP ap, const LaneOff& o, const LaneOff& oa, long l
   const long long d1 = d + nproma;
   {
     const InPtrs p = ap->nl.in;
-    L.paph_k = p.paph[o.half + d];
-    L.cur.lu_k1 = last ? 0.0 : p.lu[o.full + d1];
-    L.cur.pap = p.pap[o.full + d];
-    L.cur.q = p.q[o.full + d];
-    L.cur.t = p.t[o.full + d];
-    L.cur.l = p.l[o.clv + d];
-    L.cur.i = p.i[o.clv + d];
-    L.cur.lude = p.lude[o.full + d];
-    L.cur.mfu = p.mfu[o.full + d];
-    L.cur.mfd = p.mfd[o.full + d];
-    L.cur.gt = p.gt[o.cml + d];
-    L.cur.gq = p.gq[o.cml + d];
-    L.cur.gl = p.gl[o.cml + d];
-    L.cur.gi = p.gi[o.cml + d];
-    L.cur.supsat = p.supsat[o.full + d];
-    if (HAS_QSAT) L.cur.qsat = p.qsat[o.full + d];
+    L.paph_k = ldg(p.paph, o.half + d);
+    L.cur.lu_k1 = last ? 0.0 : ldg(p.lu, o.full + d1);
+    L.cur.pap = ldg(p.pap, o.full + d);
+    L.cur.q = ldg(p.q, o.full + d);
+    L.cur.t = ldg(p.t, o.full + d);
+    L.cur.l = ldg(p.l, o.clv + d);
+    L.cur.i = ldg(p.i, o.clv + d);
+    L.cur.lude = ldg(p.lude, o.full + d);
+    L.cur.mfu = ldg(p.mfu, o.full + d);
+    L.cur.mfd = ldg(p.mfd, o.full + d);
+    L.cur.gt = ldg(p.gt, o.cml + d);
+    L.cur.gq = ldg(p.gq, o.cml + d);
+    L.cur.gl = ldg(p.gl, o.cml + d);
+    L.cur.gi = ldg(p.gi, o.cml + d);
+    L.cur.supsat = ldg(p.supsat, o.full + d);
+    if (HAS_QSAT) L.cur.qsat = ldg(p.qsat, o.full + d);
   }
   {
     const OutPtrs po = ap->nl.out;
-    L.cy.rfl = po.fplsl[o.half + d];  // ZRFL5(JK) = PFPLSL5(JK)
-    L.cy.sfl = po.fplsn[o.half + d];
+    L.cy.rfl = ldg(po.fplsl, o.half + d);  // ZRFL5(JK) = PFPLSL5(JK)
+    L.cy.sfl = ldg(po.fplsn, o.half + d);
   }
-  L.cy.covptot = ap->nl.ckpt[osc + d];
+  L.cy.covptot = ldg(ap->nl.ckpt, osc + d);
   const OutPtrs pa = ap->aout;
-  L.ya.tent = pa.tent[oa.loc + d];
-  L.ya.tenq = pa.tenq[oa.loc + d];
-  L.ya.tenl = pa.tenl[oa.loc + d];
-  L.ya.teni = pa.teni[oa.loc + d];
-  L.ya.clc = pa.clc[oa.full + d];
-  L.ya.covptot = pa.covptot[oa.full + d];
-  L.ya.fplsn = pa.fplsn[oa.half + d1];
-  L.ya.fplsl = pa.fplsl[oa.half + d1];
-  L.ya.fhpsn = pa.fhpsn[oa.half + d1];
-  L.ya.fhpsl = pa.fhpsl[oa.half + d1];
+  L.ya.tent = ldg(pa.tent, oa.loc + d);
+  L.ya.tenq = ldg(pa.tenq, oa.loc + d);
+  L.ya.tenl = ldg(pa.tenl, oa.loc + d);
+  L.ya.teni = ldg(pa.teni, oa.loc + d);
+  L.ya.clc = ldg(pa.clc, oa.full + d);
+  L.ya.covptot = ldg(pa.covptot, oa.full + d);
+  L.ya.fplsn = ldg(pa.fplsn, oa.half + d1);
+  L.ya.fplsl = ldg(pa.fplsl, oa.half + d1);
+  L.ya.fhpsn = ldg(pa.fhpsn, oa.half + d1);
+  L.ya.fhpsl = ldg(pa.fhpsl, oa.half + d1);
   const InPtrsRW px = ap->ain;
-  L.xo.pap = px.pap[oa.full + d];
-  L.xo.q = px.q[oa.full + d];
-  L.xo.qsat = px.qsat[oa.full + d];
-  L.xo.t = px.t[oa.full + d];
-  L.xo.l = px.l[oa.clv + d];
-  L.xo.i = px.i[oa.clv + d];
-  L.xo.lude = px.lude[oa.full + d];
-  L.xo.mfu = px.mfu[oa.full + d];
-  L.xo.mfd = px.mfd[oa.full + d];
-  L.xo.gt = px.gt[oa.cml + d];
-  L.xo.gq = px.gq[oa.cml + d];
-  L.xo.gl = px.gl[oa.cml + d];
-  L.xo.gi = px.gi[oa.cml + d];
-  L.xo.lu_k1 = last ? 0.0 : px.lu[oa.full + d1];
-  L.xo.paph_k1 = last ? 0.0 : px.paph[oa.half + d1];
+  L.xo.pap = ldg(px.pap, oa.full + d);
+  L.xo.q = ldg(px.q, oa.full + d);
+  L.xo.qsat = ldg(px.qsat, oa.full + d);
+  L.xo.t = ldg(px.t, oa.full + d);
+  L.xo.l = ldg(px.l, oa.clv + d);
+  L.xo.i = ldg(px.i, oa.clv + d);
+  L.xo.lude = ldg(px.lude, oa.full + d);
+  L.xo.mfu = ldg(px.mfu, oa.full + d);
+  L.xo.mfd = ldg(px.mfd, oa.full + d);
+  L.xo.gt = ldg(px.gt, oa.cml + d);
+  L.xo.gq = ldg(px.gq, oa.cml + d);
+  L.xo.gl = ldg(px.gl, oa.cml + d);
+  L.xo.gi = ldg(px.gi, oa.cml + d);
+  L.xo.lu_k1 = last ? 0.0 : ldg(px.lu, oa.full + d1);
+  L.xo.paph_k1 = last ? 0.0 : ldg(px.paph, oa.half + d1);
 }
 
 // reverse sweep (cloudsc2ad.F90:877-1740); the trajectory pass has run before
@@ -558,40 +581,40 @@ C2_HD void ad_reverse_column(long long gcol, AdArgsP a) {
     const InPtrsRW px = ap->ain;
     const OutPtrs pa = ap->aout;
     // accumulate input adjoints (cloudsc2ad.F90:1723-1738; PSUPSAT assigned, :1733)
-    px.pap[oa.full + d] = xo.pap + ax.pap;
-    px.q[oa.full + d] = xo.q + ax.q;
-    px.qsat[oa.full + d] = xo.qsat + ax.qs;
-    px.t[oa.full + d] = xo.t + ax.t;
-    px.l[oa.clv + d] = xo.l + ax.l;
-    px.i[oa.clv + d] = xo.i + ax.i;
-    px.lude[oa.full + d] = xo.lude + ax.lude;
-    px.mfu[oa.full + d] = xo.mfu + ax.mfu;
-    px.mfd[oa.full + d] = xo.mfd + ax.mfd;
-    px.gt[oa.cml + d] = xo.gt + ax.gt;
-    px.gq[oa.cml + d] = xo.gq + ax.gq;
-    px.gl[oa.cml + d] = xo.gl + ax.gl;
-    px.gi[oa.cml + d] = xo.gi + ax.gi;
-    px.supsat[oa.full + d] = ax.supsat;
-    if (!last) px.lu[oa.full + d1] = xo.lu_k1 + ax.lu_k1;
+    stg(px.pap, oa.full + d, xo.pap + ax.pap);
+    stg(px.q, oa.full + d, xo.q + ax.q);
+    stg(px.qsat, oa.full + d, xo.qsat + ax.qs);
+    stg(px.t, oa.full + d, xo.t + ax.t);
+    stg(px.l, oa.clv + d, xo.l + ax.l);
+    stg(px.i, oa.clv + d, xo.i + ax.i);
+    stg(px.lude, oa.full + d, xo.lude + ax.lude);
+    stg(px.mfu, oa.full + d, xo.mfu + ax.mfu);
+    stg(px.mfd, oa.full + d, xo.mfd + ax.mfd);
+    stg(px.gt, oa.cml + d, xo.gt + ax.gt);
+    stg(px.gq, oa.cml + d, xo.gq + ax.gq);
+    stg(px.gl, oa.cml + d, xo.gl + ax.gl);
+    stg(px.gi, oa.cml + d, xo.gi + ax.gi);
+    stg(px.supsat, oa.full + d, ax.supsat);
+    if (!last) stg(px.lu, oa.full + d1, xo.lu_k1 + ax.lu_k1);
     surf_acc += ax.paph_surf;
     if (last) {
       surf_acc += ax.paph_k1;
     } else {
-      px.paph[oa.half + d1] = xo.paph_k1 + (ax.paph_k1 + paph_pending);
+      stg(px.paph, oa.half + d1, xo.paph_k1 + (ax.paph_k1 + paph_pending));
     }
     paph_pending = ax.paph_k;
 
     // output adjoints are consumed (cloudsc2ad.F90:917-919,955-966,1173,1572)
-    pa.tent[oa.loc + d] = 0.0;
-    pa.tenq[oa.loc + d] = 0.0;
-    pa.tenl[oa.loc + d] = 0.0;
-    pa.teni[oa.loc + d] = 0.0;
-    pa.clc[oa.full + d] = 0.0;
-    pa.covptot[oa.full + d] = 0.0;
-    pa.fplsl[oa.half + d1] = 0.0;
-    pa.fplsn[oa.half + d1] = 0.0;
-    pa.fhpsl[oa.half + d1] = 0.0;
-    pa.fhpsn[oa.half + d1] = 0.0;
+    stg(pa.tent, oa.loc + d, 0.0);
+    stg(pa.tenq, oa.loc + d, 0.0);
+    stg(pa.tenl, oa.loc + d, 0.0);
+    stg(pa.teni, oa.loc + d, 0.0);
+    stg(pa.clc, oa.full + d, 0.0);
+    stg(pa.covptot, oa.full + d, 0.0);
+    stg(pa.fplsl, oa.half + d1, 0.0);
+    stg(pa.fplsn, oa.half + d1, 0.0);
+    stg(pa.fhpsl, oa.half + d1, 0.0);
+    stg(pa.fhpsn, oa.half + d1, 0.0);
 
     paph_k1 = L.paph_k;
 #if C2_AD_PREFETCH
