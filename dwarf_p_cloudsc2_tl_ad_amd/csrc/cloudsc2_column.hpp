@@ -273,6 +273,9 @@ C2_HD void satur_column(long long gcol, SaturArgsP a) {
 // ---------------------------------------------------------------------------------------------------------
 // CKPT: the sweep is the trajectory pass of the adjoint -- it additionally checkpoints the one carry that is not an
 // output (ZCOVPTOT5(JK-1)); rain and snow flux carries are the outputs PFPLSL5/PFPLSN5 themselves.
+#ifndef C2_NL_PREFETCH_DEPTH
+#define C2_NL_PREFETCH_DEPTH 1
+#endif
 template <unsigned F>
 C2_HD void nl_column(long long gcol, NlArgsP a) {
   constexpr bool HAS_QSAT = (F & C2F_QSAT) != 0, PERT = (F & C2F_PERT) != 0, P = (F & C2F_PRECISE) != 0, CKPT = (F & C2F_CKPT) != 0, EVAP = (F & C2F_EVAP) != 0;
@@ -322,6 +325,10 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
   real_t paph_k = in->paph[o.half];
   if (PERT) paph_k = pert(paph_k, lam);
   load_level<HAS_QSAT>(in, o, nproma, nlev, 0, cur);
+#if C2_NL_PREFETCH_DEPTH == 2
+  RawLevel nx2 = cur;
+  if (nlev > 1) load_level<HAS_QSAT>(in, o, nproma, nlev, 1, nx2);
+#endif
 
   for (int jk = 0; jk < nlev; ++jk) {
     const bool last = (jk == nlev - 1);
@@ -330,8 +337,13 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
     in = &ap->in;
     // request everything level jk+1 needs now; nothing below touches `nxt` before the end of this level, so the
     // HBM latency is covered by the whole level's arithmetic
+#if C2_NL_PREFETCH_DEPTH == 2
+    nxt = nx2;  // level jk+1, requested one level ago; level jk+2 is requested now
+    if (jk + 2 < nlev) load_level<HAS_QSAT>(in, o, nproma, nlev, jk + 2, nx2);
+#else
     nxt = cur;
     if (!last) load_level<HAS_QSAT>(in, o, nproma, nlev, jk + 1, nxt);
+#endif
 
     if (!HAS_QSAT) cur.qsat = satur_point<P>(c, cur.pap, cur.t);  // SATUR on the unperturbed PAP, PT
     if (PERT) perturb_raw(cur, lam);
@@ -343,7 +355,18 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
     if (CKPT) stg(ckpt, osc + (long long)jk * nproma, cy.covptot);  // ZCOVPTOT5(JK-1)
     LevelTraj tr;
     LevelOut lo;
+#ifdef C2_SKELETON  // diagnostic build only: the memory pattern of the sweep with the physics replaced by a few adds
+    {
+      const real_t s1 = x.paph_k1 + x.pap + x.q + x.qs + x.t + x.l + x.i + x.lude;
+      const real_t s2 = x.lu_k1 + x.mfu + x.mfd + x.gt + x.gq + x.gl + x.gi + x.supsat + cy.rfl;
+      cy.rfl = s1 * 1e-9 + s2 * 1e-9;
+      lo.tent = s1; lo.tenq = s2; lo.tenl = s1 + s2; lo.teni = s1 - s2; lo.clc = s1 * 0.5; lo.covptot = s2 * 0.5;
+      lo.fplsl = cy.rfl; lo.fplsn = s1 * 0.25; lo.fhpsl = s2 * 0.25; lo.fhpsn = s1 * 0.125;
+      (void)tr; (void)k; (void)rh;
+    }
+#else
     level_forward<P, EVAP>(c, k, rh, x, cy, tr, lo);
+#endif
     C2_LAUNDER(ap);
     out = &ap->out;
     store_out(out, o, nproma, jk, lo);

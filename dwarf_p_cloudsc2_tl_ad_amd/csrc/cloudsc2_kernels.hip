@@ -147,8 +147,10 @@ __global__ void __launch_bounds__(kBlock) satur_kernel(SaturArgs args) {
   C2_KERNEL_BODY(satur_column<P>(global_column(), kernarg<SaturArgs>()));
 }
 
+// The NL variants without the evaporation branch fit 168 VGPRs (3 waves per SIMD) even with the two-level-deep
+// prefetch; asking for it keeps the allocator from spending a few registers too many.  The others take what they need.
 template <unsigned F>
-__global__ void C2_BOUNDS(C2_NL_WAVES) nl_kernel(NlArgs args) {
+__global__ void __launch_bounds__(kBlock, (C2_NL_WAVES > 0) ? C2_NL_WAVES : ((F & C2F_EVAP) ? 1 : 3)) nl_kernel(NlArgs args) {
   C2_KERNEL_BODY((nl_column<F>(global_column(), kernarg<NlArgs>())));
 }
 
