@@ -153,9 +153,7 @@ def main():
         torch.distributed.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = float(c2dist.allreduce_max([elapsed], dev)[0])  # MAX over ranks (RCCL all-reduce of one double)
     kms = np.array([a.elapsed_time(b) for a, b in ev])  # per-launch device time on the launch stream
     ms_per_step = elapsed / args.steps * 1e3
     total_cols = args.ngptot * world

@@ -27,9 +27,12 @@ def init_process_group(backend: str | None = None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # CLOUDSC2_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
+            backend = os.environ.get("CLOUDSC2_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
+        elif torch.cuda.is_available():
+            local = local % max(torch.cuda.device_count(), 1)  # rehearsal: ranks share the GPUs that exist
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
 
@@ -48,8 +51,10 @@ def allreduce_max(values, device=None) -> np.ndarray:
     v = np.atleast_1d(np.asarray(values, dtype=np.float64))
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return v
-    if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    if dist.get_backend() != "nccl":
+        device = torch.device("cpu")  # gloo (CPU tests, rehearsals): reduce on the host
+    elif device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
     t = torch.from_numpy(v.copy()).to(device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return t.cpu().numpy()
@@ -63,8 +68,10 @@ def allreduce_validation(stats: dict, device=None) -> dict:
 
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return stats
-    if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    if dist.get_backend() != "nccl":
+        device = torch.device("cpu")
+    elif device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
     names = sorted(stats)
     mn = torch.tensor([stats[n]["min"] for n in names], dtype=torch.float64, device=device)
     mx = torch.tensor([[stats[n]["max"], stats[n]["maxabserr"]] for n in names], dtype=torch.float64, device=device)
