@@ -19,6 +19,7 @@
 #include <utility>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/cloudsc2_hip.h"

@@ -146,6 +146,10 @@ int cloudsc2_adjoint_norms_launch(int nproma, int nlev, int ngptot, const clouds
  *   PT PQ TENDENCY_CML TENDENCY_LOC PAP PAPH PLU PLUDE PMFU PMFD PA PCLV PSUPSAT PCOVPTOT PFPLSL PFPLSN
  *   PFHPSL PFHPSN, with TENDENCY_* passed as the base address of B_CML / B_LOC.
  * kernel_ms (optional): device time of the kernels only (hipEvent), excluding H2D/D2H.
+ * Only what the kernels read is uploaded and only what they write is downloaded (17.5 + 12.1 KB per column);
+ * everything else keeps its host value, as under the reference.  cloudsc2_nl_run processes the blocks in slabs of
+ * ~16384 columns, uploading slab i+1 from a helper thread while slab i is computed and downloaded (kernel_ms is then
+ * the sum over the slabs' launches).
  * ------------------------------------------------------------------------------------------------ */
 int cloudsc2_nl_run(const cloudsc2_params* prm, int nproma, int nlev, int ngptot, double ptsphy,
                     const double* pt, const double* pq, const double* b_cml, double* b_loc,
