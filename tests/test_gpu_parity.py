@@ -238,6 +238,7 @@ def test_adjoint_symmetry_on_gpu():
         st = c2.state_from_table(tab, nproma, ngptot)
         zad, ok, _ = c2.run_state(prm, st, "ad")
         assert np.isfinite(zad) and ok, (nproma, ngptot, zad)
+        assert zad * np.finfo(np.float64).eps < 1e-12, zad  # BASELINE configs[3]: <TLx,y> = <x,ADy> to 1e-12
 
 
 def test_full_size_periodicity_and_determinism():
@@ -269,6 +270,55 @@ def test_full_size_periodicity_and_determinism():
             assert np.array_equal(ref, base[name]), (name, nproma)
         if base is None:
             base = {n: a.transpose(0, 2, 1).reshape(-1, a.shape[1])[:100].copy() for n, a in got.outputs().items()}
+
+
+def test_full_size_tl_ad_properties():
+    """BASELINE size (NGPTOT=160000) for the TL and the AD kernels through size-independent properties:
+    periodicity (column g == column g mod 100, bit for bit), linearity of the TL in dx, and the adjoint identity
+    <TL dx, TL dx> = <dx, AD(TL dx)> summed per column (the reference's own test, cloudsc_driver_ad_mod.F90:184-264)."""
+    import torch
+
+    tab = c2.synthetic_table()
+    prm = c2.default_params(c2.ceta_from_table(tab), lregcl=True)
+    nproma, ngptot = 128, 160000
+    ds = c2.DeviceState.from_table(tab, nproma, ngptot)
+    ds.satur(prm)
+    dx = ds.increments(zero_supsat=True)
+    dy = c2.FlatFields("out", ds.nb, ds.nlev, ds.nproma, ds.device)
+    ds.tl(prm, dx, dy)
+    torch.cuda.synchronize()
+
+    def columns(t):  # (NBLOCKS, NLEVx, NPROMA) -> (column, level)
+        return t.permute(0, 2, 1).reshape(-1, t.shape[1])[:ngptot]
+
+    # periodicity of the TL outputs
+    for n, t in dy.t.items():
+        c = columns(t)
+        assert torch.equal(c.reshape(-1, 100, c.shape[1]), c[:100].expand(ngptot // 100, 100, c.shape[1])), n
+    # linearity: TL(2 dx) == 2 TL(dx) (scaling by a power of two is exact in every product and sum)
+    dx2 = c2.FlatFields("in", ds.nb, ds.nlev, ds.nproma, ds.device)
+    for n in dx.t:
+        torch.mul(dx.t[n], 2.0, out=dx2.t[n])
+    dy2 = c2.FlatFields("out", ds.nb, ds.nlev, ds.nproma, ds.device)
+    ds.tl(prm, dx2, dy2)
+    torch.cuda.synchronize()
+    for n in dy.t:
+        assert torch.equal(dy2.t[n], 2.0 * dy.t[n]), n
+    # adjoint identity per column; the AD consumes (zeroes) its output adjoints and accumulates into zeroed input adjoints
+    norm1 = sum((columns(t) ** 2).sum(dim=1) for t in dy.t.values())
+    xa = c2.FlatFields("in", ds.nb, ds.nlev, ds.nproma, ds.device)
+    scratch = ds.new_scratch()
+    ds.ad(prm, xa, dy, scratch)
+    torch.cuda.synchronize()
+    for n, t in dy.t.items():
+        assert not t.any(), n
+    norm2 = sum((columns(dx.t[n]) * columns(xa.t[n])).sum(dim=1) for n in dx.t if n != "supsat")
+    err = ((norm1 - norm2).abs() / norm2.abs()).max().item() / np.finfo(np.float64).eps
+    assert err < 1e4, err          # the reference's threshold (cloudsc_driver_ad_mod.F90:289)
+    assert err * np.finfo(np.float64).eps < 1e-12, err  # BASELINE configs[3]: to 1e-12
+    for n, t in xa.t.items():
+        c = columns(t)
+        assert torch.equal(c.reshape(-1, 100, c.shape[1]), c[:100].expand(ngptot // 100, 100, c.shape[1])), n
 
 
 def test_strided_and_flat_layouts_agree():
