@@ -7,6 +7,8 @@
 // level JK+1 are requested before level JK is evaluated (register double buffer), which is what hides HBM latency
 // at the 2-3 waves/SIMD this fp64-heavy code runs at.
 #pragma once
+#include <type_traits>
+
 #include "cloudsc2_level.hpp"
 
 #ifndef CLOUDSC2_MAX_NLEV
@@ -68,9 +70,20 @@ typedef const C2_CONST_AS LevelTab* LevelTabP;
 typedef const C2_CONST_AS Geom* GeomP;
 typedef const C2_CONST_AS Strides* StridesP;
 
-struct LaneOff {
-  long long full, half, cml, clv, loc;
+// Per-lane offsets of the column inside each layout group.  LaneOff: element offsets (64 bit).  LaneOff32: BYTE offsets
+// in 32 bits, usable when every buffer is smaller than 4 GiB (C2F_OFF32): the accesses then take the
+// `global_load v, v_off32, s[base]` form -- no 64-bit address arithmetic per access, half the offset registers.
+template <class OT>
+struct LaneOffT {
+  OT full, half, cml, clv, loc;
 };
+typedef LaneOffT<long long> LaneOff;
+typedef LaneOffT<unsigned> LaneOff32;
+// offset of level jk / of one level row, in the units of the offset type
+C2_HD long long level_off(long long, int jk, int nproma) { return (long long)jk * nproma; }
+C2_HD unsigned level_off(unsigned, int jk, int nproma) { return (unsigned)jk * (unsigned)nproma * 8u; }
+C2_HD long long row_off(long long, int nproma) { return nproma; }
+C2_HD unsigned row_off(unsigned, int nproma) { return (unsigned)nproma * 8u; }
 
 C2_HD bool lane_setup(GeomP g, StridesP s, long long gcol, LaneOff& o, bool& active) {
   if (gcol >= g->ncols_pad) return false;
@@ -116,12 +129,29 @@ C2_HD void stg(double* p, long long i, real_t v) {
 #endif
 }
 
-template <bool HAS_QSAT>
-C2_HD void load_level(InPtrsP pp, const LaneOff& o, int nproma, int nlev, int jk, RawLevel& r) {
+C2_HD real_t ldg(const double* p, unsigned byte_off) {
+  const double* q = (const double*)((const char*)p + byte_off);
+#if C2_NT_LOAD && defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_nontemporal_load(q);
+#else
+  return *q;
+#endif
+}
+C2_HD void stg(double* p, unsigned byte_off, real_t v) {
+  double* q = (double*)((char*)p + byte_off);
+#if C2_NT_STORE && defined(__HIP_DEVICE_COMPILE__)
+  __builtin_nontemporal_store(v, q);
+#else
+  *q = v;
+#endif
+}
+
+template <bool HAS_QSAT, class OT>
+C2_HD void load_level(InPtrsP pp, const LaneOffT<OT>& o, int nproma, int nlev, int jk, RawLevel& r) {
   const InPtrs p = *pp;
-  const long long d = (long long)jk * nproma;
-  r.paph_k1 = ldg(p.paph, o.half + d + nproma);
-  r.lu_k1 = (jk + 1 < nlev) ? ldg(p.lu, o.full + d + nproma) : 0.0;
+  const OT d = level_off(OT(), jk, nproma), d1 = d + row_off(OT(), nproma);
+  r.paph_k1 = ldg(p.paph, o.half + d1);
+  r.lu_k1 = (jk + 1 < nlev) ? ldg(p.lu, o.full + d1) : 0.0;
   r.pap = ldg(p.pap, o.full + d);
   r.q = ldg(p.q, o.full + d);
   r.t = ldg(p.t, o.full + d);
@@ -203,16 +233,17 @@ C2_HD real_t tropopause(ConstsP c, LevelTabP tab, InPtrsP p, const LaneOff& o, G
 
 // All ten output pointers must be valid (the launchers substitute nothing: a skipped trajectory store is a
 // template flag of the TL kernel) -- no per-pointer branches, the pointer block is read with two wide scalar loads.
-C2_HD void store_out(OutPtrsP pp, const LaneOff& o, int nproma, int jk, const LevelOut& v) {
+template <class OT>
+C2_HD void store_out(OutPtrsP pp, const LaneOffT<OT>& o, int nproma, int jk, const LevelOut& v) {
   const OutPtrs p = *pp;
-  const long long d = (long long)jk * nproma;
+  const OT d = level_off(OT(), jk, nproma);
   stg(p.tent, o.loc + d, v.tent);
   stg(p.tenq, o.loc + d, v.tenq);
   stg(p.tenl, o.loc + d, v.tenl);
   stg(p.teni, o.loc + d, v.teni);
   stg(p.clc, o.full + d, v.clc);
   stg(p.covptot, o.full + d, v.covptot);
-  const long long d1 = d + nproma;
+  const OT d1 = d + row_off(OT(), nproma);
   stg(p.fplsl, o.half + d1, v.fplsl);
   stg(p.fplsn, o.half + d1, v.fplsn);
   stg(p.fhpsl, o.half + d1, v.fhpsl);
@@ -243,6 +274,7 @@ enum : unsigned {
   C2F_PERT = 8u,     // NL only: inputs perturbed by lambda*0.01*x (Taylor test)
   C2F_CKPT = 16u,    // NL only: trajectory pass of the adjoint (carry checkpoints)
   C2F_TRAJ = 8u,     // TL only: trajectory outputs are stored
+  C2F_OFF32 = 32u,   // NL only: every buffer < 4 GiB, 32-bit byte offsets (LaneOff32)
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -279,6 +311,8 @@ C2_HD void satur_column(long long gcol, SaturArgsP a) {
 template <unsigned F>
 C2_HD void nl_column(long long gcol, NlArgsP a) {
   constexpr bool HAS_QSAT = (F & C2F_QSAT) != 0, PERT = (F & C2F_PERT) != 0, P = (F & C2F_PRECISE) != 0, CKPT = (F & C2F_CKPT) != 0, EVAP = (F & C2F_EVAP) != 0;
+  constexpr bool OFF32 = (F & C2F_OFF32) != 0;
+  typedef typename std::conditional<OFF32, unsigned, long long>::type OT;
   static_assert(!(PERT && CKPT), "the adjoint's trajectory pass is never perturbed");
   LaneOff o; bool active;
   if (!lane_setup(&a->g, &a->s, gcol, o, active)) return;
@@ -324,10 +358,20 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
   RawLevel cur, nxt;
   real_t paph_k = in->paph[o.half];
   if (PERT) paph_k = pert(paph_k, lam);
-  load_level<HAS_QSAT>(in, o, nproma, nlev, 0, cur);
+  // offsets used inside the level loop, in the variant's offset type
+  LaneOffT<OT> ol;
+  OT ozl, oscl;
+  if (OFF32) {
+    ol.full = (OT)(o.full * 8); ol.half = (OT)(o.half * 8); ol.cml = (OT)(o.cml * 8); ol.clv = (OT)(o.clv * 8);
+    ol.loc = (OT)(o.loc * 8); ozl = (OT)(ozero * 8); oscl = (OT)(osc * 8);
+  } else {
+    ol.full = (OT)o.full; ol.half = (OT)o.half; ol.cml = (OT)o.cml; ol.clv = (OT)o.clv; ol.loc = (OT)o.loc;
+    ozl = (OT)ozero; oscl = (OT)osc;
+  }
+  load_level<HAS_QSAT>(in, ol, nproma, nlev, 0, cur);
 #if C2_NL_PREFETCH_DEPTH == 2
   RawLevel nx2 = cur;
-  if (nlev > 1) load_level<HAS_QSAT>(in, o, nproma, nlev, 1, nx2);
+  if (nlev > 1) load_level<HAS_QSAT>(in, ol, nproma, nlev, 1, nx2);
 #endif
 
   for (int jk = 0; jk < nlev; ++jk) {
@@ -339,10 +383,10 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
     // HBM latency is covered by the whole level's arithmetic
 #if C2_NL_PREFETCH_DEPTH == 2
     nxt = nx2;  // level jk+1, requested one level ago; level jk+2 is requested now
-    if (jk + 2 < nlev) load_level<HAS_QSAT>(in, o, nproma, nlev, jk + 2, nx2);
+    if (jk + 2 < nlev) load_level<HAS_QSAT>(in, ol, nproma, nlev, jk + 2, nx2);
 #else
     nxt = cur;
-    if (!last) load_level<HAS_QSAT>(in, o, nproma, nlev, jk + 1, nxt);
+    if (!last) load_level<HAS_QSAT>(in, ol, nproma, nlev, jk + 1, nxt);
 #endif
 
     if (!HAS_QSAT) cur.qsat = satur_point<P>(c, cur.pap, cur.t);  // SATUR on the unperturbed PAP, PT
@@ -352,7 +396,7 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
     level_cst(tab, jk, last, k);
     LevelIn x;
     make_level_in(cur, paph_k, paph_surf, x);
-    if (CKPT) stg(ckpt, osc + (long long)jk * nproma, cy.covptot);  // ZCOVPTOT5(JK-1)
+    if (CKPT) stg(ckpt, oscl + level_off(OT(), jk, nproma), cy.covptot);  // ZCOVPTOT5(JK-1)
     LevelTraj tr;
     LevelOut lo;
 #ifdef C2_SKELETON  // diagnostic build only: the memory pattern of the sweep with the physics replaced by a few adds
@@ -369,8 +413,8 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
 #endif
     C2_LAUNDER(ap);
     out = &ap->out;
-    store_out(out, o, nproma, jk, lo);
-    if (zero_plane) stg(zero_plane, ozero + (long long)jk * nproma, 0.0);
+    store_out(out, ol, nproma, jk, lo);
+    if (zero_plane) stg(zero_plane, ozl + level_off(OT(), jk, nproma), 0.0);
     paph_k = cur.paph_k1;
     cur = nxt;
   }

@@ -184,7 +184,7 @@ template <class Args> using KernelFn = void (*)(Args);
   template <unsigned... F> constexpr std::array<KernelFn<Args>, sizeof...(F)> table##_make(                        \
       std::integer_sequence<unsigned, F...>) { return {{table##_entry<F>()...}}; }                                 \
   [[maybe_unused]] const std::array<KernelFn<Args>, NF> table = table##_make(std::make_integer_sequence<unsigned, NF>{});
-C2_VARIANT_TABLE(g_nl_kernels, nl_kernel, NlArgs, 32, !((F & C2F_PERT) && (F & C2F_CKPT)) && (C2_AD_FUSED ? !(F & C2F_CKPT) : true))
+C2_VARIANT_TABLE(g_nl_kernels, nl_kernel, NlArgs, 64, !((F & C2F_PERT) && (F & C2F_CKPT)) && (C2_AD_FUSED ? !(F & C2F_CKPT) : true))
 C2_VARIANT_TABLE(g_tl_kernels, tl_kernel, TlArgs, 16, true)
 C2_VARIANT_TABLE(g_ad_reverse_kernels, ad_reverse_kernel, AdArgs, 8, !C2_AD_FUSED)
 C2_VARIANT_TABLE(g_ad_kernels, ad_kernel, AdArgs, 8, C2_AD_FUSED != 0)
@@ -548,6 +548,14 @@ int cloudsc2_nl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
   if (pert_lambda != 0.0) f |= C2F_PERT;
   if (g_precise.load()) f |= C2F_PRECISE;
   if (args.c.evap) f |= C2F_EVAP;
+  // 32-bit byte offsets when every buffer the sweep touches is smaller than 4 GiB
+  {
+    const long long nb = g.ncols_pad / nproma;
+    const long long span = std::max({s.full, s.half, s.cml, s.clv, s.loc, (long long)zero_plane.block_stride}) * nb +
+                           (long long)nproma * (nlev + 2);
+    static const bool allow32 = !(getenv("CLOUDSC2_OFF32") && atoi(getenv("CLOUDSC2_OFF32")) == 0);  // 0: measurements only
+    if (allow32 && span * 8 < (1LL << 32)) f |= C2F_OFF32;
+  }
   return launch_variant(g_nl_kernels[f], args, g.ncols_pad, (hipStream_t)stream);
 }
 

@@ -20,7 +20,11 @@ static void hc_dispatch(unsigned f, long long gc, const A* a) {
     else hc_dispatch<Fn, N, F + 1>(f, gc, a);
   }
 }
-template <unsigned F> struct HcNl { static void run(long long gc, const NlArgs* a) { nl_column<F>(gc, a); } };
+template <unsigned F> struct HcNl {
+  static void run(long long gc, const NlArgs* a) {
+    if constexpr (!((F & C2F_PERT) && (F & C2F_CKPT))) nl_column<F>(gc, a);
+  }
+};
 template <unsigned F> struct HcTl { static void run(long long gc, const TlArgs* a) { tl_column<F>(gc, a); } };
 template <unsigned F> struct HcAd {
   static void run(long long gc, const AdArgs* a) { nl_column<F | C2F_CKPT>(gc, &a->nl); ad_reverse_column<F>(gc, a); }
@@ -63,10 +67,12 @@ static Geom hc_geom(int nproma, int nlev, int ngptot) {
 }
 
 static int g_hc_precise = 0;
+static int g_hc_off32 = 0;
 
 extern "C" {
 
 void hostcheck_set_precise(int p) { g_hc_precise = p; }
+void hostcheck_set_off32(int v) { g_hc_off32 = v; }  // NL: 32-bit byte offsets (C2F_OFF32)
 
 int hostcheck_satur(const cloudsc2_params* prm, int nproma, int nlev, int ngptot, cloudsc2_field pap, cloudsc2_field t,
                     cloudsc2_field qsat) {
@@ -90,8 +96,8 @@ int hostcheck_nl(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev
   hc_in(*in, a.s, a.in); hc_out(*out, a.s, a.out);
   a.zero_plane = zero_plane.ptr; a.zero_stride = zero_plane.block_stride; a.lam = lam; a.ckpt = nullptr;
   unsigned f = (in->qsat.ptr ? C2F_QSAT : 0u) | (lam != 0.0 ? C2F_PERT : 0u) | (g_hc_precise ? C2F_PRECISE : 0u) |
-               (a.c.evap ? C2F_EVAP : 0u);
-  for (long long gc = 0; gc < a.g.ncols_pad; ++gc) hc_dispatch<HcNl, 16>(f, gc, &a);
+               (a.c.evap ? C2F_EVAP : 0u) | (g_hc_off32 ? C2F_OFF32 : 0u);
+  for (long long gc = 0; gc < a.g.ncols_pad; ++gc) hc_dispatch<HcNl, 64>(f, gc, &a);
   return 0;
 }
 

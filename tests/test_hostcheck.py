@@ -52,6 +52,19 @@ def test_nl_columns(oracle, nproma, ngptot):
     zero.ptr = got.B_LOC.ctypes.data + 8 * 7 * S
     zero.block_stride = 8 * S
     assert hostcheck().hostcheck_nl(C.byref(prm), st.ptsphy, nproma, st.nlev, ngptot, C.byref(i), C.byref(o), zero, 0.0) == 0
+    # the 32-bit byte-offset variant of the sweep (C2F_OFF32) must give the same bits
+    got32 = st.copy()
+    i32, o32 = host_traj_blocks(got32)
+    zero32 = B.Field()
+    zero32.ptr = got32.B_LOC.ctypes.data + 8 * 7 * S
+    zero32.block_stride = 8 * S
+    hostcheck().hostcheck_set_off32(1)
+    try:
+        assert hostcheck().hostcheck_nl(C.byref(prm), st.ptsphy, nproma, st.nlev, ngptot, C.byref(i32), C.byref(o32), zero32, 0.0) == 0
+    finally:
+        hostcheck().hostcheck_set_off32(0)
+    for n in ("B_LOC", "PA", "PCOVPTOT", "PFPLSL", "PFPLSN", "PFHPSL", "PFHPSN"):
+        assert np.array_equal(getattr(got, n), getattr(got32, n)), n
     for ibl in range(st.nblocks):
         icend = min(nproma, ngptot - ibl * nproma)
         qs = oracle.satur(np.ascontiguousarray(st.PAP[ibl]), np.ascontiguousarray(st.PT[ibl]), kfdia=icend)

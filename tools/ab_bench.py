@@ -8,6 +8,7 @@ import statistics
 import subprocess
 import sys
 
+# a "lib" may carry environment settings: "path.so,NAME=VALUE,..."
 libs, kernels, sizes = sys.argv[1].split(), sys.argv[2].split(), sys.argv[3].split()
 rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 res = {}
@@ -15,7 +16,8 @@ for r in range(rounds):
     for k in kernels:
         for n in sizes:
             for lib in libs:
-                env = dict(os.environ, CLOUDSC2_LIB=lib)
+                parts = lib.split(",")
+                env = dict(os.environ, CLOUDSC2_LIB=parts[0], **dict(kv.split("=") for kv in parts[1:]))
                 out = subprocess.run([sys.executable, "bench.py", "--kernel", k, "--ngptot", n, "--steps", "20", "--warmup", "3",
                                       "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300).stdout
                 d = json.loads(out.strip().split("\n")[-1])
