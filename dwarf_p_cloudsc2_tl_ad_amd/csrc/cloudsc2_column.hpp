@@ -85,6 +85,15 @@ C2_HD unsigned level_off(unsigned, int jk, int nproma) { return (unsigned)jk * (
 C2_HD long long row_off(long long, int nproma) { return nproma; }
 C2_HD unsigned row_off(unsigned, int nproma) { return (unsigned)nproma * 8u; }
 
+// element offsets -> the offset type of a kernel variant (bytes for LaneOff32)
+template <class OT>
+C2_HD LaneOffT<OT> lane_off_as(const LaneOff& o) {
+  const long long m = sizeof(OT) == 4 ? 8 : 1;
+  LaneOffT<OT> r;
+  r.full = (OT)(o.full * m); r.half = (OT)(o.half * m); r.cml = (OT)(o.cml * m); r.clv = (OT)(o.clv * m); r.loc = (OT)(o.loc * m);
+  return r;
+}
+
 C2_HD bool lane_setup(GeomP g, StridesP s, long long gcol, LaneOff& o, bool& active) {
   if (gcol >= g->ncols_pad) return false;
   long long ibl = gcol / g->nproma;
@@ -274,7 +283,7 @@ enum : unsigned {
   C2F_PERT = 8u,     // NL only: inputs perturbed by lambda*0.01*x (Taylor test)
   C2F_CKPT = 16u,    // NL only: trajectory pass of the adjoint (carry checkpoints)
   C2F_TRAJ = 8u,     // TL only: trajectory outputs are stored
-  C2F_OFF32 = 32u,   // NL only: every buffer < 4 GiB, 32-bit byte offsets (LaneOff32)
+  C2F_OFF32 = 32u,   // NL, TL: every buffer < 4 GiB, 32-bit byte offsets (LaneOff32)
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -359,15 +368,8 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
   real_t paph_k = in->paph[o.half];
   if (PERT) paph_k = pert(paph_k, lam);
   // offsets used inside the level loop, in the variant's offset type
-  LaneOffT<OT> ol;
-  OT ozl, oscl;
-  if (OFF32) {
-    ol.full = (OT)(o.full * 8); ol.half = (OT)(o.half * 8); ol.cml = (OT)(o.cml * 8); ol.clv = (OT)(o.clv * 8);
-    ol.loc = (OT)(o.loc * 8); ozl = (OT)(ozero * 8); oscl = (OT)(osc * 8);
-  } else {
-    ol.full = (OT)o.full; ol.half = (OT)o.half; ol.cml = (OT)o.cml; ol.clv = (OT)o.clv; ol.loc = (OT)o.loc;
-    ozl = (OT)ozero; oscl = (OT)osc;
-  }
+  const LaneOffT<OT> ol = lane_off_as<OT>(o);
+  const OT ozl = (OT)(ozero * (OFF32 ? 8 : 1)), oscl = (OT)(osc * (OFF32 ? 8 : 1));
   load_level<HAS_QSAT>(in, ol, nproma, nlev, 0, cur);
 #if C2_NL_PREFETCH_DEPTH == 2
   RawLevel nx2 = cur;
@@ -429,6 +431,7 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
 template <unsigned F>
 C2_HD void tl_column(long long gcol, TlArgsP a) {
   constexpr bool HAS_QSAT = (F & C2F_QSAT) != 0, P = (F & C2F_PRECISE) != 0, STORE_TRAJ = (F & C2F_TRAJ) != 0, EVAP = (F & C2F_EVAP) != 0;
+  typedef typename std::conditional<(F & C2F_OFF32) != 0, unsigned, long long>::type OT;
   LaneOff o, op; bool active;
   if (!lane_setup(&a->g, &a->s, gcol, o, active)) return;
   lane_setup(&a->g, &a->sp, gcol, op, active);
@@ -456,8 +459,9 @@ C2_HD void tl_column(long long gcol, TlArgsP a) {
   Carry dcy; dcy.rfl = 0.0; dcy.sfl = 0.0; dcy.covptot = 0.0;
   RawLevel cur, nxt, dcur, dnxt;
   real_t paph_k = in->paph[o.half], dpaph_k = din->paph[op.half];
-  load_level<HAS_QSAT>(in, o, nproma, nlev, 0, cur);
-  load_level<true>(din, op, nproma, nlev, 0, dcur);
+  const LaneOffT<OT> ol = lane_off_as<OT>(o), opl = lane_off_as<OT>(op);  // offsets used inside the level loop
+  load_level<HAS_QSAT>(in, ol, nproma, nlev, 0, cur);
+  load_level<true>(din, opl, nproma, nlev, 0, dcur);
 
   for (int jk = 0; jk < nlev; ++jk) {
     const bool last = (jk == nlev - 1);
@@ -467,13 +471,13 @@ C2_HD void tl_column(long long gcol, TlArgsP a) {
 #if C2_TL_PREFETCH
     nxt = cur; dnxt = dcur;
     if (!last) {
-      load_level<HAS_QSAT>(in, o, nproma, nlev, jk + 1, nxt);
-      load_level<true>(din, op, nproma, nlev, jk + 1, dnxt);
+      load_level<HAS_QSAT>(in, ol, nproma, nlev, jk + 1, nxt);
+      load_level<true>(din, opl, nproma, nlev, jk + 1, dnxt);
     }
 #else
     if (jk > 0) {
-      load_level<HAS_QSAT>(in, o, nproma, nlev, jk, cur);
-      load_level<true>(din, op, nproma, nlev, jk, dcur);
+      load_level<HAS_QSAT>(in, ol, nproma, nlev, jk, cur);
+      load_level<true>(din, opl, nproma, nlev, jk, dcur);
     }
 #endif
     if (!HAS_QSAT) cur.qsat = satur_point<P>(c, cur.pap, cur.t);
@@ -489,8 +493,8 @@ C2_HD void tl_column(long long gcol, TlArgsP a) {
     level_tl(c, k, x, tr, dx, dcy, dlo);
     C2_LAUNDER(ap);
     out = &ap->out; dout = &ap->dout;
-    if (STORE_TRAJ) store_out(out, o, nproma, jk, lo);
-    store_out(dout, op, nproma, jk, dlo);
+    if (STORE_TRAJ) store_out(out, ol, nproma, jk, lo);
+    store_out(dout, opl, nproma, jk, dlo);
     paph_k = cur.paph_k1; dpaph_k = dcur.paph_k1;
 #if C2_TL_PREFETCH
     cur = nxt;

@@ -14,6 +14,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <initializer_list>
 #include <array>
 #include <atomic>
 #include <utility>
@@ -185,7 +186,7 @@ template <class Args> using KernelFn = void (*)(Args);
       std::integer_sequence<unsigned, F...>) { return {{table##_entry<F>()...}}; }                                 \
   [[maybe_unused]] const std::array<KernelFn<Args>, NF> table = table##_make(std::make_integer_sequence<unsigned, NF>{});
 C2_VARIANT_TABLE(g_nl_kernels, nl_kernel, NlArgs, 64, !((F & C2F_PERT) && (F & C2F_CKPT)) && (C2_AD_FUSED ? !(F & C2F_CKPT) : true))
-C2_VARIANT_TABLE(g_tl_kernels, tl_kernel, TlArgs, 16, true)
+C2_VARIANT_TABLE(g_tl_kernels, tl_kernel, TlArgs, 64, !(F & 16u))
 C2_VARIANT_TABLE(g_ad_reverse_kernels, ad_reverse_kernel, AdArgs, 8, !C2_AD_FUSED)
 C2_VARIANT_TABLE(g_ad_kernels, ad_kernel, AdArgs, 8, C2_AD_FUSED != 0)
 
@@ -439,6 +440,14 @@ int check_geom(const cloudsc2_params* prm, int nproma, int nlev, int ngptot, Geo
   return 0;
 }
 
+// 32-bit byte offsets (C2F_OFF32) are usable when every buffer the sweep touches is smaller than 4 GiB
+bool fits_off32(const Geom& g, int nproma, int nlev, std::initializer_list<long long> strides) {
+  static const bool allow32 = !(getenv("CLOUDSC2_OFF32") && atoi(getenv("CLOUDSC2_OFF32")) == 0);  // 0: measurements only
+  const long long nb = g.ncols_pad / nproma;
+  const long long span = std::max(strides) * nb + (long long)nproma * (nlev + 2);
+  return allow32 && span * 8 < (1LL << 32);
+}
+
 inline unsigned grid_for(long long ncols, int block) { return (unsigned)((ncols + block - 1) / block); }
 
 template <class Args>
@@ -548,14 +557,7 @@ int cloudsc2_nl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
   if (pert_lambda != 0.0) f |= C2F_PERT;
   if (g_precise.load()) f |= C2F_PRECISE;
   if (args.c.evap) f |= C2F_EVAP;
-  // 32-bit byte offsets when every buffer the sweep touches is smaller than 4 GiB
-  {
-    const long long nb = g.ncols_pad / nproma;
-    const long long span = std::max({s.full, s.half, s.cml, s.clv, s.loc, (long long)zero_plane.block_stride}) * nb +
-                           (long long)nproma * (nlev + 2);
-    static const bool allow32 = !(getenv("CLOUDSC2_OFF32") && atoi(getenv("CLOUDSC2_OFF32")) == 0);  // 0: measurements only
-    if (allow32 && span * 8 < (1LL << 32)) f |= C2F_OFF32;
-  }
+  if (fits_off32(g, nproma, nlev, {s.full, s.half, s.cml, s.clv, s.loc, (long long)zero_plane.block_stride})) f |= C2F_OFF32;
   return launch_variant(g_nl_kernels[f], args, g.ncols_pad, (hipStream_t)stream);
 }
 
@@ -588,6 +590,7 @@ int cloudsc2_tl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
   if (store_traj) f |= C2F_TRAJ;
   if (g_precise.load()) f |= C2F_PRECISE;
   if (args.c.evap) f |= C2F_EVAP;
+  if (fits_off32(g, nproma, nlev, {s.full, s.half, s.cml, s.clv, s.loc, sp.full, sp.half, sp.cml, sp.clv, sp.loc})) f |= C2F_OFF32;
   return launch_variant(g_tl_kernels[f], args, g.ncols_pad, (hipStream_t)stream);
 }
 

@@ -321,6 +321,42 @@ def test_full_size_tl_ad_properties():
         assert torch.equal(c.reshape(-1, 100, c.shape[1]), c[:100].expand(ngptot // 100, 100, c.shape[1])), n
 
 
+def test_offset_variants_give_the_same_bits(tmp_path):
+    """The launchers pick 32-bit byte offsets (C2F_OFF32) whenever every buffer is below 4 GiB, i.e. in every other test
+    of this file; CLOUDSC2_OFF32=0 forces the 64-bit variants that large states use.  Both must produce identical bits
+    (the choice is read once per process, hence the two child processes)."""
+    import os
+    import subprocess
+    import sys
+
+    from tests.util import ROOT
+
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import dwarf_p_cloudsc2_tl_ad_amd as c2\n"
+        "tab = c2.random_table(137, 100, seed=4)\n"
+        "prm = c2.default_params(c2.ceta_from_table(tab))\n"
+        "ds = c2.DeviceState.from_table(tab, 64, 1000)\n"
+        "ds.nl(prm); ds.satur(prm)\n"
+        "dx = ds.increments(); dy = c2.FlatFields('out', ds.nb, ds.nlev, ds.nproma, ds.device)\n"
+        "ds.tl(prm, dx, dy); torch.cuda.synchronize()\n"
+        "out = {n: getattr(ds, n).cpu().numpy() for n in ('B_LOC', 'PA', 'PFPLSL', 'PFPLSN', 'PFHPSL', 'PFHPSN')}\n"
+        "out.update({'tl_' + n: t.cpu().numpy() for n, t in dy.t.items()})\n"
+        "np.savez(sys.argv[1], **out)\n" % ROOT)
+    files = []
+    for mode in ("0", "1"):
+        f = str(tmp_path / f"off32_{mode}.npz")
+        r = subprocess.run([sys.executable, "-c", code, f], env={**os.environ, "CLOUDSC2_OFF32": mode}, capture_output=True,
+                           text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        files.append(np.load(f))
+    assert set(files[0].files) == set(files[1].files) and len(files[0].files) == 16
+    for n in files[0].files:
+        assert np.array_equal(files[0][n], files[1][n]), n
+    assert np.any(files[0]["tl_tent"] != 0.0)
+
+
 def test_strided_and_flat_layouts_agree():
     """The kernel-level ABI accepts any block stride per layout group: AoSoA planes (driver layout) and flat arrays
     must give identical results."""
