@@ -5,7 +5,7 @@
 // Memory access: lane g reads f[jl + NPROMA*(jk + NLEVx*ibl)] with g = ibl*NPROMA + jl, i.e. consecutive lanes
 // read consecutive doubles of every plane -> a wave64 fetches 512 contiguous bytes per plane and level.  Inputs of
 // level JK+1 are requested before level JK is evaluated (register double buffer), which is what hides HBM latency
-// at the 2-3 waves/SIMD this fp64-heavy code runs at.
+// at the 1-3 waves/SIMD this fp64-heavy code runs at (NL 3, TL and AD 1).
 #pragma once
 #include <type_traits>
 

@@ -9,18 +9,19 @@
 // appear only in the two test-norm kernels.
 #include <hip/hip_runtime.h>
 #include <math.h>
-#include <cmath>
 #include <stdio.h>
-#include <string.h>
 #include <stdlib.h>
+#include <string.h>
+
 #include <algorithm>
-#include <initializer_list>
 #include <array>
 #include <atomic>
-#include <utility>
+#include <cmath>
+#include <initializer_list>
 #include <mutex>
 #include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "../../include/cloudsc2_hip.h"

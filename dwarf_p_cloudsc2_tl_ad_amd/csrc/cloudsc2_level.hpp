@@ -45,7 +45,7 @@ typedef double real_t;
 // fp64 math building blocks.  The level costs ~50 divisions, ~12 exp and a tanh in the reference formulation
 // (SURVEY.md 8d); on CDNA4 an IEEE fp64 division is ~13 instructions around a quarter-rate v_rcp_f64, so the
 // arithmetic, not HBM, bounds the kernel.  Hence: reciprocals are taken with v_rcp_f64 + one third-order step and
-// shared / batch-inverted (Montgomery) between quotients, exp is a branch-free Cody-Waite + degree-13 kernel,
+// shared / batch-inverted (Montgomery) between quotients, exp is a 15-instruction branch-free kernel (c2_exp),
 // tanh comes from one exp.  Results differ from correctly rounded ones by a few ulp (parity tolerance: 1e-10).
 // ---------------------------------------------------------------------------------------------------------
 C2_HD real_t c2_rcp(real_t x) {
@@ -258,7 +258,7 @@ typedef const C2_CONST_AS Consts* ConstsP;
 // C2_PIN_DEF=0: "s" inputs -- the values stay rematerialisable: under SGPR pressure the allocator re-issues the s_load
 // inside divergent branches (one more exposed wait each) instead of spilling.  C2_PIN_DEF=1: "+s" -- the values become
 // definitions of the asm statement and are parked in VGPR lanes under pressure (v_readlane at the use, no wait).
-// Which is faster is kernel-specific and was measured: 0 for NL, 1 for TL and AD.
+// Measured equal within noise for all three kernels once the constants were grouped into stage blocks; 0 is built.
 #ifndef C2_PIN_DEF
 #define C2_PIN_DEF 0
 #endif
