@@ -120,7 +120,7 @@ def main():
     if args.kernel == "nl":
         step = lambda: ds.nl(prm, stream)  # noqa: E731
         bpc = c2.bytes_per_column(nlev, "nl_driver")
-        kname = "nl_kernel<0> (SATUR + CLOUDSC2 fused, fast math, no evaporation branch)"
+        kname = "nl_kernel<F> (SATUR + CLOUDSC2 fused; fast math, no evaporation branch, 32-bit offsets when buffers < 4 GiB)"
     else:
         ds.satur(prm, stream)
         inc = ds.increments(zero_supsat=(args.kernel == "ad"))
