@@ -314,9 +314,6 @@ C2_HD void satur_column(long long gcol, SaturArgsP a) {
 // ---------------------------------------------------------------------------------------------------------
 // CKPT: the sweep is the trajectory pass of the adjoint -- it additionally checkpoints the one carry that is not an
 // output (ZCOVPTOT5(JK-1)); rain and snow flux carries are the outputs PFPLSL5/PFPLSN5 themselves.
-#ifndef C2_NL_UNROLL2
-#define C2_NL_UNROLL2 0  // two levels per trip (no copy of the prefetched set): measured 3-18 % slower, kept for reference
-#endif
 template <unsigned F>
 C2_HD void nl_column(long long gcol, NlArgsP a) {
   constexpr bool HAS_QSAT = (F & C2F_QSAT) != 0, PERT = (F & C2F_PERT) != 0, P = (F & C2F_PRECISE) != 0, CKPT = (F & C2F_CKPT) != 0, EVAP = (F & C2F_EVAP) != 0;
@@ -409,16 +406,9 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
 
   RawLevel ra, rb;
   load_level<HAS_QSAT>(in, ol, nproma, nlev, 0, ra);
-  int jk = 0;
-#if C2_NL_UNROLL2  // the two register sets swap roles
+  rb = ra;
 #pragma clang loop unroll(disable)
-  for (; jk + 1 < nlev; jk += 2) {
-    step(jk, ra, rb);
-    step(jk + 1, rb, ra);
-  }
-#endif
-#pragma clang loop unroll(disable)
-  for (; jk < nlev; ++jk) {
+  for (int jk = 0; jk < nlev; ++jk) {
     step(jk, ra, rb);
     ra = rb;
   }
@@ -427,9 +417,6 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
 // ---------------------------------------------------------------------------------------------------------
 // TL: SATUR (optionally fused) + CLOUDSC2TL for one column
 // ---------------------------------------------------------------------------------------------------------
-#ifndef C2_TL_PREFETCH
-#define C2_TL_PREFETCH 1
-#endif
 template <unsigned F>
 C2_HD void tl_column(long long gcol, TlArgsP a) {
   constexpr bool HAS_QSAT = (F & C2F_QSAT) != 0, P = (F & C2F_PRECISE) != 0, STORE_TRAJ = (F & C2F_TRAJ) != 0, EVAP = (F & C2F_EVAP) != 0;
@@ -470,18 +457,11 @@ C2_HD void tl_column(long long gcol, TlArgsP a) {
     TlArgsP ap = a;
     C2_LAUNDER(ap);
     in = &ap->in; din = &ap->din;
-#if C2_TL_PREFETCH
     nxt = cur; dnxt = dcur;
     if (!last) {
       load_level<HAS_QSAT>(in, ol, nproma, nlev, jk + 1, nxt);
       load_level<true>(din, opl, nproma, nlev, jk + 1, dnxt);
     }
-#else
-    if (jk > 0) {
-      load_level<HAS_QSAT>(in, ol, nproma, nlev, jk, cur);
-      load_level<true>(din, opl, nproma, nlev, jk, dcur);
-    }
-#endif
     if (!HAS_QSAT) cur.qsat = satur_point<P>(c, cur.pap, cur.t);
 
     LevelCst k;
@@ -498,10 +478,8 @@ C2_HD void tl_column(long long gcol, TlArgsP a) {
     if (STORE_TRAJ) store_out(out, ol, nproma, jk, lo);
     store_out(dout, opl, nproma, jk, dlo);
     paph_k = cur.paph_k1; dpaph_k = dcur.paph_k1;
-#if C2_TL_PREFETCH
     cur = nxt;
     dcur = dnxt;
-#endif
   }
 }
 
@@ -511,9 +489,6 @@ C2_HD void tl_column(long long gcol, TlArgsP a) {
 // written anyway, the precipitation cover goes to the scratch plane).  The reverse pass below re-evaluates each
 // level's trajectory from its checkpoint and applies the transposed level.
 // ---------------------------------------------------------------------------------------------------------
-#ifndef C2_AD_PREFETCH
-#define C2_AD_PREFETCH 0
-#endif
 
 // Everything the reverse pass reads for level jk: trajectory inputs, the three checkpointed carries, the output
 // adjoints, and the OLD values of the input adjoints that are accumulated into.  (Written as `a[i] += x` after the
@@ -614,23 +589,13 @@ C2_HD void ad_reverse_column(long long gcol, AdArgsP a) {
   real_t surf_acc = 0.0;      // PAPHP1(KLEV+1) adjoint, written once at the end
   real_t paph_k1 = paph_bottom;
   AdLevelLoads L;
-#if C2_AD_PREFETCH
-  ad_load_level<HAS_QSAT>(a, o, oa, osc, nproma, nlev, nlev - 1, L);
-#endif
   for (int jk = nlev - 1; jk >= 0; --jk) {
     const bool last = (jk == nlev - 1);
     const long long d = (long long)jk * nproma;
     const long long d1 = d + nproma;
     AdArgsP ap = a;
     C2_LAUNDER(ap);
-#if C2_AD_PREFETCH
-    // level jk-1 is requested before level jk is evaluated; none of level jk's stores touches what it reads
-    // (different level index in every plane), so issuing the loads first is safe and the compiler keeps the order
-    AdLevelLoads N = L;
-    if (jk > 0) ad_load_level<HAS_QSAT>(ap, o, oa, osc, nproma, nlev, jk - 1, N);
-#else
     ad_load_level<HAS_QSAT>(ap, o, oa, osc, nproma, nlev, jk, L);
-#endif
     RawLevel& cur = L.cur;
     cur.paph_k1 = paph_k1;
     const RawLevel& xo = L.xo;
@@ -690,9 +655,6 @@ C2_HD void ad_reverse_column(long long gcol, AdArgsP a) {
     stg(pa.fhpsn, oa.half + d1, 0.0);
 
     paph_k1 = L.paph_k;
-#if C2_AD_PREFETCH
-    L = N;
-#endif
   }
   InPtrsRWP ain = &a->ain;
   OutPtrsP aout = &a->aout;

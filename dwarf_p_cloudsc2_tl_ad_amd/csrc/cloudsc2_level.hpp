@@ -255,22 +255,12 @@ typedef const C2_CONST_AS Consts* ConstsP;
 // uses them into 64-byte blocks; a stage copies its block with ONE s_load_dwordx16 and pins it (C2_PIN8), i.e. one
 // wait per stage, and the SGPRs are free again afterwards.
 #if defined(__HIP_DEVICE_COMPILE__)
-// C2_PIN_DEF=0: "s" inputs -- the values stay rematerialisable: under SGPR pressure the allocator re-issues the s_load
-// inside divergent branches (one more exposed wait each) instead of spilling.  C2_PIN_DEF=1: "+s" -- the values become
-// definitions of the asm statement and are parked in VGPR lanes under pressure (v_readlane at the use, no wait).
-// Measured equal within noise for all three kernels once the constants were grouped into stage blocks; 0 is built.
-#ifndef C2_PIN_DEF
-#define C2_PIN_DEF 0
-#endif
-#if C2_PIN_DEF == 1
-#define C2_PIN8(b) asm volatile("" : "+s"((b).v[0]), "+s"((b).v[1]), "+s"((b).v[2]), "+s"((b).v[3]), "+s"((b).v[4]), \
-                                 "+s"((b).v[5]), "+s"((b).v[6]), "+s"((b).v[7]))
-#define C2_PIN2(x, y) asm volatile("" : "+s"(x), "+s"(y))
-#else
+// The pins are "s" INPUTS of an empty asm statement: the values stay rematerialisable, i.e. under SGPR pressure the
+// allocator re-issues the s_load inside a divergent branch instead of spilling.  ("+s" operands, which turn the values
+// into definitions that get parked in VGPR lanes under pressure, measured the same within noise.)
 #define C2_PIN8(b) asm volatile("" ::"s"((b).v[0]), "s"((b).v[1]), "s"((b).v[2]), "s"((b).v[3]), "s"((b).v[4]), "s"((b).v[5]), \
                                  "s"((b).v[6]), "s"((b).v[7]))
 #define C2_PIN2(x, y) asm volatile("" ::"s"(x), "s"(y))
-#endif
 #else
 #define C2_PIN8(b) ((void)0)
 #define C2_PIN2(x, y) ((void)0)
