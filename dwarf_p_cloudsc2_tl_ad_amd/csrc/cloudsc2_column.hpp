@@ -283,7 +283,7 @@ enum : unsigned {
   C2F_PERT = 8u,     // NL only: inputs perturbed by lambda*0.01*x (Taylor test)
   C2F_CKPT = 16u,    // NL only: trajectory pass of the adjoint (carry checkpoints)
   C2F_TRAJ = 8u,     // TL only: trajectory outputs are stored
-  C2F_OFF32 = 32u,   // NL, TL: every buffer < 4 GiB, 32-bit byte offsets (LaneOff32)
+  C2F_OFF32 = 32u,   // every buffer of the launch < 4 GiB: 32-bit byte offsets (LaneOff32)
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -502,12 +502,12 @@ struct AdLevelLoads {
   RawLevel xo;    // old input adjoints (PSUPSAT is assigned, not accumulated: not read)
 };
 
-template <bool HAS_QSAT>
-C2_HD void ad_load_level(AdArgsP ap, const LaneOff& o, const LaneOff& oa, long long osc, int nproma, int nlev, int jk,
+template <bool HAS_QSAT, class OT>
+C2_HD void ad_load_level(AdArgsP ap, const LaneOffT<OT>& o, const LaneOffT<OT>& oa, OT osc, int nproma, int nlev, int jk,
                          AdLevelLoads& L) {
   const bool last = (jk == nlev - 1);
-  const long long d = (long long)jk * nproma;
-  const long long d1 = d + nproma;
+  const OT d = level_off(OT(), jk, nproma);
+  const OT d1 = d + row_off(OT(), nproma);
   {
     const InPtrs p = ap->nl.in;
     L.paph_k = ldg(p.paph, o.half + d);
@@ -566,9 +566,11 @@ C2_HD void ad_load_level(AdArgsP ap, const LaneOff& o, const LaneOff& oa, long l
 template <unsigned F>
 C2_HD void ad_reverse_column(long long gcol, AdArgsP a) {
   constexpr bool HAS_QSAT = (F & C2F_QSAT) != 0, P = (F & C2F_PRECISE) != 0, EVAP = (F & C2F_EVAP) != 0;
-  LaneOff o, oa; bool active;
+  constexpr bool OFF32 = (F & C2F_OFF32) != 0;
+  typedef typename std::conditional<OFF32, unsigned, long long>::type OT;
+  LaneOff o, oa64; bool active;
   if (!lane_setup(&a->nl.g, &a->nl.s, gcol, o, active)) return;
-  lane_setup(&a->nl.g, &a->sa, gcol, oa, active);
+  lane_setup(&a->nl.g, &a->sa, gcol, oa64, active);
   if (!active) return;
   const int nlev = a->nl.g.nlev, nproma = a->nl.g.nproma;
   LevelTabP tab = (LevelTabP)a->nl.tab;
@@ -576,7 +578,10 @@ C2_HD void ad_reverse_column(long long gcol, AdArgsP a) {
   InPtrsP in = &a->nl.in;
 
   // scratch: (NPROMA, NLEV, NBLOCKS) contiguous
-  const long long osc = (gcol / nproma) * ((long long)nproma * nlev) + (gcol % nproma);
+  const long long osc64 = (gcol / nproma) * ((long long)nproma * nlev) + (gcol % nproma);
+  // offsets used inside the level loop, in the variant's offset type
+  const LaneOffT<OT> ol = lane_off_as<OT>(o), oa = lane_off_as<OT>(oa64);
+  const OT osc = (OT)(osc64 * (OFF32 ? 8 : 1));
 
   real_t ztrpaus = tropopause<false>(c, tab, in, o, &a->nl.g, 0.0);
   RhCrit rh;
@@ -591,11 +596,11 @@ C2_HD void ad_reverse_column(long long gcol, AdArgsP a) {
   AdLevelLoads L;
   for (int jk = nlev - 1; jk >= 0; --jk) {
     const bool last = (jk == nlev - 1);
-    const long long d = (long long)jk * nproma;
-    const long long d1 = d + nproma;
+    const OT d = level_off(OT(), jk, nproma);
+    const OT d1 = d + row_off(OT(), nproma);
     AdArgsP ap = a;
     C2_LAUNDER(ap);
-    ad_load_level<HAS_QSAT>(ap, o, oa, osc, nproma, nlev, jk, L);
+    ad_load_level<HAS_QSAT>(ap, ol, oa, osc, nproma, nlev, jk, L);
     RawLevel& cur = L.cur;
     cur.paph_k1 = paph_k1;
     const RawLevel& xo = L.xo;
@@ -658,13 +663,13 @@ C2_HD void ad_reverse_column(long long gcol, AdArgsP a) {
   }
   InPtrsRWP ain = &a->ain;
   OutPtrsP aout = &a->aout;
-  ain->paph[oa.half] += paph_pending;
-  ain->paph[oa.half + (long long)nlev * nproma] += surf_acc;
+  ain->paph[oa64.half] += paph_pending;
+  ain->paph[oa64.half + (long long)nlev * nproma] += surf_acc;
   // the adjoint of the (constant zero) top fluxes is discarded (cloudsc2ad.F90:1678-1679,917-919)
-  aout->fplsl[oa.half] = 0.0;
-  aout->fplsn[oa.half] = 0.0;
-  aout->fhpsl[oa.half] = 0.0;
-  aout->fhpsn[oa.half] = 0.0;
+  aout->fplsl[oa64.half] = 0.0;
+  aout->fplsn[oa64.half] = 0.0;
+  aout->fhpsl[oa64.half] = 0.0;
+  aout->fhpsn[oa64.half] = 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------------------

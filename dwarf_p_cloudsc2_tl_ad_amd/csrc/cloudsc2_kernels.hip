@@ -188,8 +188,8 @@ template <class Args> using KernelFn = void (*)(Args);
   [[maybe_unused]] const std::array<KernelFn<Args>, NF> table = table##_make(std::make_integer_sequence<unsigned, NF>{});
 C2_VARIANT_TABLE(g_nl_kernels, nl_kernel, NlArgs, 64, !((F & C2F_PERT) && (F & C2F_CKPT)) && (C2_AD_FUSED ? !(F & C2F_CKPT) : true))
 C2_VARIANT_TABLE(g_tl_kernels, tl_kernel, TlArgs, 64, !(F & 16u))
-C2_VARIANT_TABLE(g_ad_reverse_kernels, ad_reverse_kernel, AdArgs, 8, !C2_AD_FUSED)
-C2_VARIANT_TABLE(g_ad_kernels, ad_kernel, AdArgs, 8, C2_AD_FUSED != 0)
+C2_VARIANT_TABLE(g_ad_reverse_kernels, ad_reverse_kernel, AdArgs, 64, !C2_AD_FUSED && !(F & 24u))
+C2_VARIANT_TABLE(g_ad_kernels, ad_kernel, AdArgs, 64, C2_AD_FUSED != 0 && !(F & 24u))
 
 // ---------------------------------------------------------------------------------------------------------
 // Data-format kernels either side of the path: the input file holds KLON (=100) columns,
@@ -625,6 +625,8 @@ int cloudsc2_ad_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
   if (traj_in->qsat.ptr) f |= C2F_QSAT;
   if (g_precise.load()) f |= C2F_PRECISE;
   if (args.nl.c.evap) f |= C2F_EVAP;
+  if (fits_off32(g, nproma, nlev, {s.full, s.half, s.cml, s.clv, s.loc, sa.full, sa.half, sa.cml, sa.clv, sa.loc,
+                                  (long long)nproma * nlev /* scratch */})) f |= C2F_OFF32;
 #if C2_AD_FUSED
   return launch_variant(g_ad_kernels[f], args, g.ncols_pad, (hipStream_t)stream);
 #else

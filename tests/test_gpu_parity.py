@@ -343,6 +343,9 @@ def test_offset_variants_give_the_same_bits(tmp_path):
         "ds.tl(prm, dx, dy); torch.cuda.synchronize()\n"
         "out = {n: getattr(ds, n).cpu().numpy() for n in ('B_LOC', 'PA', 'PFPLSL', 'PFPLSN', 'PFHPSL', 'PFHPSN')}\n"
         "out.update({'tl_' + n: t.cpu().numpy() for n, t in dy.t.items()})\n"
+        "xa = c2.FlatFields('in', ds.nb, ds.nlev, ds.nproma, ds.device); sc = ds.new_scratch()\n"
+        "ds.ad(prm, xa, dy, sc); torch.cuda.synchronize()\n"
+        "out.update({'ad_' + n: t.cpu().numpy() for n, t in xa.t.items()})\n"
         "np.savez(sys.argv[1], **out)\n" % ROOT)
     files = []
     for mode in ("0", "1"):
@@ -351,10 +354,10 @@ def test_offset_variants_give_the_same_bits(tmp_path):
                            text=True, timeout=300)
         assert r.returncode == 0, r.stderr
         files.append(np.load(f))
-    assert set(files[0].files) == set(files[1].files) and len(files[0].files) == 16
+    assert set(files[0].files) == set(files[1].files) and len(files[0].files) == 32
     for n in files[0].files:
         assert np.array_equal(files[0][n], files[1][n]), n
-    assert np.any(files[0]["tl_tent"] != 0.0)
+    assert np.any(files[0]["tl_tent"] != 0.0) and np.any(files[0]["ad_t"] != 0.0)
 
 
 def test_strided_and_flat_layouts_agree():
