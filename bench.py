@@ -86,6 +86,19 @@ def cpu_baseline(tab, prm, nproma, ngptot, budget_s=20.0):
                       f"({best * 1e3:.0f} ms each), OMP_SCHEDULE=static"}
 
 
+def device_info(torch, dev):
+    """What the box is (boxes of one pool measure up to 12 % apart with the same binary)."""
+    try:
+        p = torch.cuda.get_device_properties(dev)
+        info = {"name": p.name, "compute_units": p.multi_processor_count, "hbm_gib": round(p.total_memory / 2**30, 1)}
+        for k in ("clock_rate", "memory_clock_rate", "gcnArchName"):
+            if hasattr(p, k):
+                info[k] = getattr(p, k)
+        return info
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,7 +198,8 @@ def main():
         "config": {"workload": f"CLOUDSC2 {args.kernel.upper()} fp64, NGPTOT={args.ngptot} columns per GPU, NLEV=137, "
                                f"NPROMA={args.nproma} (BASELINE.json configs[1])",
                    "ngptot_per_gpu": args.ngptot, "nlev": nlev, "nproma": args.nproma,
-                   "parallelism": f"columns sharded over {world} GPU(s), no data-path collective"},
+                   "parallelism": f"columns sharded over {world} GPU(s), no data-path collective",
+                   "device": device_info(torch, dev)},
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.kernel == "nl":
