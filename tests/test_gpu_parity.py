@@ -199,6 +199,28 @@ def test_tl_ad_kernels_match_checker(flags, nproma, ngptot):
     # (PSUPSAT excluded: the reference assigns its adjoint with a spurious PTSPHY factor, cloudsc2ad.F90:1733)
 
 
+@pytest.mark.parametrize("nlev", [11, 60, 200])
+def test_other_numbers_of_levels(nlev):
+    """NLEV other than 137 (the kernels take it at run time; CETA holds up to 200 levels): NL through the driver, TL and
+    AD at kernel level, against the checker.  With 11 levels the tropopause band is empty."""
+    tab = c2.random_table(nlev, 64, seed=9)
+    prm = c2.default_params(c2.ceta_from_table(tab))
+    st = c2.state_from_table(tab, 64, 100, poison_outputs=3.0)
+    chk = checker()
+    set_lib_params(chk, prm)
+    want = ref_nl_state(chk, st, prm)
+    got = st.copy()
+    c2.run_state(prm, got, "nl")
+    assert_outputs_close(want, got, NL_TOL)
+    r = _device_tl_ad(tab, 64, 100, {})
+    act = lambda a: np.concatenate([a[ibl][:, : min(64, 100 - ibl * 64)] for ibl in range(2)], axis=1)  # noqa: E731
+    for n in r["tl_ref"]:
+        assert relerr(act(r["tl_ref"][n]), act(r["tl_dev"][n])) <= TLAD_TOL, ("tl", n)
+    for n in r["x_ref"]:
+        scale = max(np.abs(act(r["x_ref"][n])).max(), 1e-300)
+        assert np.abs(act(r["x_dev"][n]) - act(r["x_ref"][n])).max() / scale <= TLAD_TOL, ("ad", n)
+
+
 def test_taylor_test_passes_on_gpu():
     """CLOUDSC_DRIVER_TL semantics (cloudsc_driver_tl_mod.F90:272-311): V-shaped convergence of the Taylor ratio."""
     tab = c2.synthetic_table()

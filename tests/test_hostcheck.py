@@ -79,9 +79,12 @@ def test_nl_columns(oracle, nproma, ngptot):
     assert np.all(got.PCOVPTOT == 0.0) and np.all(got.B_LOC[:, 7] == 0.0)
 
 
-@pytest.mark.parametrize("flags", [dict(), dict(lregcl=True), dict(levapls2=True, lregcl=True), dict(ldrain1d=True)])
-def test_tl_ad_columns(oracle, flags):
-    tab = c2.random_table(137, 30, seed=4)
+@pytest.mark.parametrize("flags,nlev", [(dict(), 137), (dict(lregcl=True), 137), (dict(levapls2=True, lregcl=True), 137),
+                                        (dict(ldrain1d=True), 137), (dict(), 60), (dict(levapls2=True, lregcl=True), 200),
+                                        (dict(), 11)])
+def test_tl_ad_columns(oracle, flags, nlev):
+    """NLEV other than 137: the level tables, the tropopause band (empty for very few levels) and CETA(200) bounds."""
+    tab = c2.random_table(nlev, 30, seed=4)
     prm = make_params(tab, **flags)
     set_lib_params(oracle, prm)
     nproma, ngptot = 16, 30
