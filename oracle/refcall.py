@@ -111,7 +111,9 @@ class _KernelLib:
         klev, klon = inp["pap"].shape
         out = out if out is not None else new_outputs(klev, klon)
         args = kernel_arg_order(inp, out)
-        getattr(self.lib, self.prefix + "cloudsc2")(1, kfdia or klon, klon, klev, int(ldrain1d), float(ptsphy), *[_p(a) for a in args])
+        # the kernels keep (KLON,KLEV) work arrays on the stack (cloudsc2.F90:176-190): large KLON needs a large stack
+        big_stack(getattr(self.lib, self.prefix + "cloudsc2"), 1, kfdia or klon, klon, klev, int(ldrain1d), float(ptsphy),
+                  *[_p(a) for a in args])
         return out
 
     def cloudsc2tl(self, ptsphy: float, inp5: dict, dinp: dict, out5: dict | None = None, dout: dict | None = None,
@@ -120,7 +122,8 @@ class _KernelLib:
         out5 = out5 if out5 is not None else new_outputs(klev, klon)
         dout = dout if dout is not None else new_outputs(klev, klon)
         args = kernel_arg_order(inp5, out5) + kernel_arg_order(dinp, dout)
-        getattr(self.lib, self.prefix + "cloudsc2tl")(1, kfdia or klon, klon, klev, int(ldrain1d), float(ptsphy), *[_p(a) for a in args])
+        big_stack(getattr(self.lib, self.prefix + "cloudsc2tl"), 1, kfdia or klon, klon, klev, int(ldrain1d), float(ptsphy),
+                  *[_p(a) for a in args])
         return out5, dout
 
     def cloudsc2ad(self, ptsphy: float, inp5: dict, ainp: dict, aout: dict, out5: dict | None = None, ldrain1d=False,
