@@ -204,3 +204,31 @@ def test_fortran_main_loads_validates_and_writes_reference(tmp_path):
     lines = [ln for ln in out.split("\n") if re.fullmatch(r"\dD\d", ln[22:25])]
     assert len(lines) == 10 and all(ln[22:25] in ("2D1", "3D1") for ln in lines), out
     torch.cuda.synchronize()
+
+
+def test_cpp_host_example_prints_the_same_report(tmp_path):
+    """examples/cloudsc2_resident.cpp (plain C++ on the C ABI: file -> device tiling -> NL -> device validation) must
+    print exactly the report the Python driver produces for the same files."""
+    import os
+    import subprocess
+
+    from tests.util import ROOT
+
+    exe = os.path.join(ROOT, "examples", "build", "cloudsc2_resident")
+    if not os.path.exists(exe):
+        pytest.fail(f"{exe} missing: run __graft_entry__.build()")
+    tab = c2.synthetic_table()
+    prm = c2.default_params(c2.ceta_from_table(tab))
+    prm.nlev = 137
+    ref = golden_reference_table(tab)
+    fileio.write_input_file(str(tmp_path / "input.h5"), tab, prm)
+    fileio.write_reference_file(str(tmp_path / "reference.h5"), ref)
+    nproma, ngptot = 128, 20000
+    r = subprocess.run([exe, str(ngptot), str(nproma)], cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr  # 4 would mean a "!!!!" line
+    assert "columns/s" in r.stderr
+    tab2, prm2 = fileio.read_input_file(str(tmp_path / "input.h5"))
+    ds = c2.DeviceState.from_table(tab2, nproma, ngptot)
+    ds.nl(prm2)
+    _, text = ds.validate(ref)
+    assert r.stdout.rstrip("\n") == text
