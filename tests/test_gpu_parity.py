@@ -7,7 +7,6 @@ libm, so agreement is expected at ~1e-13 and the tests assert 1e-10 (NL), 1e-9 (
 """
 from __future__ import annotations
 
-import ctypes as C
 
 import numpy as np
 import pytest
