@@ -382,6 +382,44 @@ def test_offset_variants_give_the_same_bits(tmp_path):
     assert np.any(files[0]["tl_tent"] != 0.0) and np.any(files[0]["ad_t"] != 0.0)
 
 
+def test_results_do_not_depend_on_the_blocking():
+    """A column's result must not depend on NPROMA (which block and which lane it lands in): NL, TL and AD outputs per
+    global column are compared bit for bit across awkward block sizes, ragged tails included."""
+    import torch
+
+    tab = c2.random_table(137, 100, seed=13)
+    prm = c2.default_params(c2.ceta_from_table(tab), lregcl=True)
+    ngptot = 3001
+
+    def run(nproma):
+        ds = c2.DeviceState.from_table(tab, nproma, ngptot)
+        ds.nl(prm)
+        ds.satur(prm)
+        dx = ds.increments(zero_supsat=True)
+        dy = c2.FlatFields("out", ds.nb, ds.nlev, ds.nproma, ds.device)
+        ds.tl(prm, dx, dy)
+        y = {n: t.clone() for n, t in dy.t.items()}
+        xa = c2.FlatFields("in", ds.nb, ds.nlev, ds.nproma, ds.device)
+        ds.ad(prm, xa, dy, ds.new_scratch())
+        torch.cuda.synchronize()
+
+        def cols(t):  # (NBLOCKS, NLEVx, NPROMA) -> (column, level)
+            return t.permute(0, 2, 1).reshape(-1, t.shape[1])[:ngptot].cpu().numpy()
+
+        out = {"nl_" + n: cols(getattr(ds, n)) for n in ("PA", "PFPLSL", "PFPLSN", "PFHPSL", "PFHPSN")}
+        out.update({f"nl_bloc{p}": cols(ds.B_LOC[:, p]) for p in (0, 2, 3, 4)})
+        out.update({"tl_" + n: cols(t) for n, t in y.items()})
+        out.update({"ad_" + n: cols(t) for n, t in xa.t.items()})
+        return out
+
+    base = run(128)
+    assert np.any(base["ad_t"] != 0.0) and np.any(base["tl_tent"] != 0.0)
+    for nproma in (1, 7, 33, 63, 65, 96, 127, 129, 257, 1000, 4000):
+        got = run(nproma)
+        for n in base:
+            assert np.array_equal(base[n], got[n]), (nproma, n)
+
+
 def test_strided_and_flat_layouts_agree():
     """The kernel-level ABI accepts any block stride per layout group: AoSoA planes (driver layout) and flat arrays
     must give identical results."""
