@@ -170,7 +170,9 @@ def test_fortran_main_loads_validates_and_writes_reference(tmp_path):
     fileio.write_input_file(str(run / "input.h5"), tab, prm)
     fileio.write_reference_file(str(run / "reference.h5"), ref)
     nproma, ngptot = 128, 16300
-    out, _ = _run_fortran("dwarf-cloudsc2-nl", 1, ngptot, nproma, cwd=str(run))
+    c2.set_math_mode(False)  # parent and children in the same (default) math mode whatever CLOUDSC2_MATH says
+    fast = {"CLOUDSC2_MATH": "fast"}
+    out, _ = _run_fortran("dwarf-cloudsc2-nl", 1, ngptot, nproma, cwd=str(run), env=fast)
     lines = [ln for ln in out.split("\n") if ln.strip()]
     i0 = next(i for i, ln in enumerate(lines) if ln == B.validate_header())
     table = lines[i0 + 1:i0 + 11]
@@ -189,7 +191,7 @@ def test_fortran_main_loads_validates_and_writes_reference(tmp_path):
     wr = tmp_path / "write"
     wr.mkdir()
     fileio.write_input_file(str(wr / "input.h5"), tab, prm)
-    out, _ = _run_fortran("dwarf-cloudsc2-nl", 1, 300, 64, cwd=str(wr), env={"CLOUDSC2_WRITE_REFERENCE": "1"})
+    out, _ = _run_fortran("dwarf-cloudsc2-nl", 1, 300, 64, cwd=str(wr), env={"CLOUDSC2_WRITE_REFERENCE": "1", **fast})
     assert os.path.exists(wr / "reference.h5")
     back = fileio.read_reference_file(str(wr / "reference.h5"))
     st = c2.state_from_table(tab, 64, 300)
@@ -198,7 +200,7 @@ def test_fortran_main_loads_validates_and_writes_reference(tmp_path):
     for n in fileio.REFERENCE_FIELDS:
         assert np.array_equal(back[n], mine[n]), n
     # and a run validated against the file it has just written reports exact agreement
-    out, _ = _run_fortran("dwarf-cloudsc2-nl", 1, 1000, 32, cwd=str(wr))
+    out, _ = _run_fortran("dwarf-cloudsc2-nl", 1, 1000, 32, cwd=str(wr), env=fast)
     import re
 
     lines = [ln for ln in out.split("\n") if re.fullmatch(r"\dD\d", ln[22:25])]
@@ -224,7 +226,9 @@ def test_cpp_host_example_prints_the_same_report(tmp_path):
     fileio.write_input_file(str(tmp_path / "input.h5"), tab, prm)
     fileio.write_reference_file(str(tmp_path / "reference.h5"), ref)
     nproma, ngptot = 128, 20000
-    r = subprocess.run([exe, str(ngptot), str(nproma)], cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    c2.set_math_mode(False)
+    r = subprocess.run([exe, str(ngptot), str(nproma)], cwd=str(tmp_path), capture_output=True, text=True, timeout=300,
+                       env={**os.environ, "CLOUDSC2_MATH": "fast"})
     assert r.returncode == 0, r.stdout + r.stderr  # 4 would mean a "!!!!" line
     assert "columns/s" in r.stderr
     tab2, prm2 = fileio.read_input_file(str(tmp_path / "input.h5"))
