@@ -5,7 +5,12 @@
 tag=${1:-ev}; out=gpurun_out/$tag; mkdir -p $out
 timeout -k 10 900 python -m pytest tests -m gpu -q > $out/pytest_gpu.log 2>&1; tail -2 $out/pytest_gpu.log
 timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1 && echo smoke ok || { echo smoke FAILED; tail -5 $out/smoke.log; }
+# what the box is and how it clocks while the kernel runs (boxes of the pool measure up to 12 % apart)
+rocm-smi --showproductname --showclocks --showpower --showperflevel --showmemvendor > $out/rocm_smi_idle.txt 2>&1
+(for i in 1 2 3 4 5 6 7 8; do sleep 2; rocm-smi --showclocks --showpower --showtemp 2>/dev/null | grep -E "sclk|mclk|fclk|Power|Temperature" | tr '\n' ';'; echo; done > $out/rocm_smi_during_bench.txt) &
+smi_pid=$!
 timeout -k 10 600 python bench.py > $out/bench_default.json 2> $out/bench_default.err && cat $out/bench_default.json || exit 1
+wait $smi_pid
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $out/bench_prof.json 2> $out/bench_prof.err || exit 1
 for n in 160000 1048576; do
   PMC_NGPTOT=$n timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_$n -- python3 tools/pmc_workload.py > $out/pmc_fetch_$n.log 2>&1 || exit 1
