@@ -114,7 +114,7 @@ def main():
     ap.add_argument("--kernel", choices=["nl", "tl", "ad"], default="nl")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--levapls2", action="store_true", help="switch the evaporation branch on (off in every shipped config)")
-    ap.add_argument("--placement-regions", default="0,50,100,150,200",
+    ap.add_argument("--placement-regions", default="0,30,60,90,120,150,180,210",
                     help="GiB offsets in HBM at which candidate placements of the state are timed before the measurement "
                          "(the fastest is used; '0' = just allocate)")
     args = ap.parse_args()
