@@ -15,8 +15,21 @@ CLOUDSC2_MAX_NLEV = 200
 CLOUDSC2_EINVAL, CLOUDSC2_ENODEVICE, CLOUDSC2_ETLWRONG = -1, -2, -3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+# CLOUDSC2_PRECISION=single: the process works on fp32 arrays through libcloudsc2_hip_sp.so -- the counterpart of
+# building the reference with -DSINGLE (JPRB = JPRM, src/common/module/parkind1.F90:40-41).  Like there, it is a
+# whole-program choice: one process, one precision.
+SINGLE = os.environ.get("CLOUDSC2_PRECISION", "double").strip().lower() in ("single", "sp", "f32", "fp32", "float32")
+REAL = np.float32 if SINGLE else np.float64
+REAL_BYTES = 4 if SINGLE else 8
+c_real = C.c_float if SINGLE else C.c_double
 # CLOUDSC2_LIB: load another build of the same library (kernel-tuning experiments)
-LIB_PATH = os.environ.get("CLOUDSC2_LIB") or os.path.join(_HERE, "csrc", "libcloudsc2_hip.so")
+LIB_PATH = os.environ.get("CLOUDSC2_LIB") or os.path.join(_HERE, "csrc", "libcloudsc2_hip_sp.so" if SINGLE else "libcloudsc2_hip.so")
+
+
+def torch_real():
+    import torch
+
+    return torch.float32 if SINGLE else torch.float64
 
 
 class Cloudsc2Error(RuntimeError):
@@ -90,7 +103,11 @@ def _load() -> C.CDLL:
         pass
     lib = C.CDLL(LIB_PATH)
     dp = C.POINTER(C.c_double)
+    rp = C.POINTER(c_real)  # cloudsc2_real*
     pp = C.POINTER(Params)
+    lib.cloudsc2_real_bytes.restype = C.c_int
+    if lib.cloudsc2_real_bytes() != REAL_BYTES:
+        raise ImportError(f"{LIB_PATH} works on {lib.cloudsc2_real_bytes()}-byte reals, CLOUDSC2_PRECISION asks for {REAL_BYTES}")
     lib.cloudsc2_params_default.argtypes = [pp]
     lib.cloudsc2_params_default.restype = None
     lib.cloudsc2_last_error.restype = C.c_char_p
@@ -110,14 +127,14 @@ def _load() -> C.CDLL:
     lib.cloudsc2_adjoint_norms_launch.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(Inputs), C.POINTER(Field),
                                                   C.POINTER(Outputs), C.POINTER(Inputs), C.c_void_p, C.c_void_p,
                                                   C.c_void_p]
-    host18 = [dp] * 18
+    host18 = [rp] * 18
     lib.cloudsc2_nl_run.argtypes = [pp, C.c_int, C.c_int, C.c_int, C.c_double] + host18 + [dp]
     lib.cloudsc2_tl_taylor_run.argtypes = [pp, C.c_int, C.c_int, C.c_int, C.c_double] + host18 + [dp, dp]
     lib.cloudsc2_ad_symmetry_run.argtypes = [pp, C.c_int, C.c_int, C.c_int, C.c_double] + host18 + [dp, dp]
     lib.cloudsc2_release_workspace.restype = None
     lib.cloudsc2_taylor_verdict.argtypes = [dp, C.POINTER(C.c_int)]
     lib.cloudsc2_adjoint_verdict.argtypes = [C.c_double]
-    expand_args = [dp, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_longlong, Field]
+    expand_args = [rp, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_longlong, Field]
     lib.cloudsc2_expand_launch.argtypes = expand_args + [C.c_void_p]
     lib.cloudsc2_validate_workspace_doubles.restype = C.c_int
     lib.cloudsc2_validate_launch.argtypes = expand_args + [dp, dp, C.c_void_p]
@@ -141,7 +158,7 @@ lib = _load()
 
 # every symbol include/cloudsc2_hip.h declares
 EXPORTED = ("cloudsc2_params_default", "cloudsc2_last_error", "cloudsc2_device_available", "cloudsc2_set_math_mode",
-            "cloudsc2_get_math_mode", "cloudsc2_nl_launch",
+            "cloudsc2_get_math_mode", "cloudsc2_real_bytes", "cloudsc2_nl_launch",
             "cloudsc2_satur_launch", "cloudsc2_tl_launch", "cloudsc2_ad_launch", "cloudsc2_taylor_sums_launch",
             "cloudsc2_adjoint_norms_launch", "cloudsc2_nl_run", "cloudsc2_tl_taylor_run", "cloudsc2_ad_symmetry_run",
             "cloudsc2_release_workspace", "cloudsc2_taylor_verdict", "cloudsc2_adjoint_verdict",

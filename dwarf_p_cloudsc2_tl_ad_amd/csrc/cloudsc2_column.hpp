@@ -19,7 +19,7 @@ namespace cloudsc2 {
 
 // per-level, column-independent tables (device copy)
 struct LevelTab {
-  struct { double ceta, zscalm; } lev[CLOUDSC2_MAX_NLEV];  // interleaved: one 16-byte scalar load per level
+  struct { real_t ceta, zscalm; } lev[CLOUDSC2_MAX_NLEV];  // interleaved: one 16-byte scalar load per level
 };
 
 struct Geom {
@@ -36,21 +36,21 @@ struct Strides {
 };
 
 struct InPtrs {
-  const double *paph, *pap, *q, *qsat, *t, *l, *i, *lude, *lu, *mfu, *mfd, *gt, *gq, *gl, *gi, *supsat;
+  const real_t *paph, *pap, *q, *qsat, *t, *l, *i, *lude, *lu, *mfu, *mfd, *gt, *gq, *gl, *gi, *supsat;
 };
 struct OutPtrs {
-  double *tent, *tenq, *tenl, *teni, *clc, *fplsl, *fplsn, *fhpsl, *fhpsn, *covptot;
+  real_t *tent, *tenq, *tenl, *teni, *clc, *fplsl, *fplsn, *fhpsl, *fhpsn, *covptot;
 };
 struct InPtrsRW {
-  double *paph, *pap, *q, *qsat, *t, *l, *i, *lude, *lu, *mfu, *mfd, *gt, *gq, *gl, *gi, *supsat;
+  real_t *paph, *pap, *q, *qsat, *t, *l, *i, *lude, *lu, *mfu, *mfd, *gt, *gq, *gl, *gi, *supsat;
 };
 
 // Kernel argument blocks.  Each kernel takes exactly one of these by value; on the device the column functions read
 // it in place from the kernel-argument segment through a constant-address-space pointer (see C2_LAUNDER).
 struct NlArgs {
   Consts c; Geom g; Strides s; InPtrs in; OutPtrs out; const LevelTab* tab;
-  double* zero_plane; long long zero_stride; real_t lam;
-  double* ckpt;  // CKPT kernels only: (NPROMA,NLEV,NBLOCKS) plane receiving the precipitation cover carried INTO each level
+  real_t* zero_plane; long long zero_stride; real_t lam;
+  real_t* ckpt;  // CKPT kernels only: (NPROMA,NLEV,NBLOCKS) plane receiving the precipitation cover carried INTO each level
 };
 struct TlArgs {
   Consts c; Geom g; Strides s, sp; InPtrs in; OutPtrs out; InPtrs din; OutPtrs dout; const LevelTab* tab;
@@ -81,14 +81,14 @@ typedef LaneOffT<long long> LaneOff;
 typedef LaneOffT<unsigned> LaneOff32;
 // offset of level jk / of one level row, in the units of the offset type
 C2_HD long long level_off(long long, int jk, int nproma) { return (long long)jk * nproma; }
-C2_HD unsigned level_off(unsigned, int jk, int nproma) { return (unsigned)jk * (unsigned)nproma * 8u; }
+C2_HD unsigned level_off(unsigned, int jk, int nproma) { return (unsigned)jk * (unsigned)nproma * (unsigned)sizeof(real_t); }
 C2_HD long long row_off(long long, int nproma) { return nproma; }
-C2_HD unsigned row_off(unsigned, int nproma) { return (unsigned)nproma * 8u; }
+C2_HD unsigned row_off(unsigned, int nproma) { return (unsigned)nproma * (unsigned)sizeof(real_t); }
 
 // element offsets -> the offset type of a kernel variant (bytes for LaneOff32)
 template <class OT>
 C2_HD LaneOffT<OT> lane_off_as(const LaneOff& o) {
-  const long long m = sizeof(OT) == 4 ? 8 : 1;
+  const long long m = sizeof(OT) == 4 ? (long long)sizeof(real_t) : 1;
   LaneOffT<OT> r;
   r.full = (OT)(o.full * m); r.half = (OT)(o.half * m); r.cml = (OT)(o.cml * m); r.clv = (OT)(o.clv * m); r.loc = (OT)(o.loc * m);
   return r;
@@ -123,14 +123,14 @@ struct RawLevel {
 #ifndef C2_NT_STORE
 #define C2_NT_STORE 1
 #endif
-C2_HD real_t ldg(const double* p, long long i) {
+C2_HD real_t ldg(const real_t* p, long long i) {
 #if C2_NT_LOAD && defined(__HIP_DEVICE_COMPILE__)
   return __builtin_nontemporal_load(p + i);
 #else
   return p[i];
 #endif
 }
-C2_HD void stg(double* p, long long i, real_t v) {
+C2_HD void stg(real_t* p, long long i, real_t v) {
 #if C2_NT_STORE && defined(__HIP_DEVICE_COMPILE__)
   __builtin_nontemporal_store(v, p + i);
 #else
@@ -138,16 +138,16 @@ C2_HD void stg(double* p, long long i, real_t v) {
 #endif
 }
 
-C2_HD real_t ldg(const double* p, unsigned byte_off) {
-  const double* q = (const double*)((const char*)p + byte_off);
+C2_HD real_t ldg(const real_t* p, unsigned byte_off) {
+  const real_t* q = (const real_t*)((const char*)p + byte_off);
 #if C2_NT_LOAD && defined(__HIP_DEVICE_COMPILE__)
   return __builtin_nontemporal_load(q);
 #else
   return *q;
 #endif
 }
-C2_HD void stg(double* p, unsigned byte_off, real_t v) {
-  double* q = (double*)((char*)p + byte_off);
+C2_HD void stg(real_t* p, unsigned byte_off, real_t v) {
+  real_t* q = (real_t*)((char*)p + byte_off);
 #if C2_NT_STORE && defined(__HIP_DEVICE_COMPILE__)
   __builtin_nontemporal_store(v, q);
 #else
@@ -160,7 +160,7 @@ C2_HD void load_level(InPtrsP pp, const LaneOffT<OT>& o, int nproma, int nlev, i
   const InPtrs p = *pp;
   const OT d = level_off(OT(), jk, nproma), d1 = d + row_off(OT(), nproma);
   r.paph_k1 = ldg(p.paph, o.half + d1);
-  r.lu_k1 = (jk + 1 < nlev) ? ldg(p.lu, o.full + d1) : 0.0;
+  r.lu_k1 = (jk + 1 < nlev) ? ldg(p.lu, o.full + d1) : RC(0.0);
   r.pap = ldg(p.pap, o.full + d);
   r.q = ldg(p.q, o.full + d);
   r.t = ldg(p.t, o.full + d);
@@ -178,7 +178,7 @@ C2_HD void load_level(InPtrsP pp, const LaneOffT<OT>& o, int nproma, int nlev, i
 }
 
 // Perturbed state of the Taylor test: x5 = x + lambda*(0.01*x) (cloudsc_driver_tl_mod.F90:156-171,200-215).
-C2_HD real_t pert(real_t x, real_t lam) { return x + lam * (x * 0.01); }
+C2_HD real_t pert(real_t x, real_t lam) { return x + lam * (x * RC(0.01)); }
 
 C2_HD void perturb_raw(RawLevel& r, real_t lam) {
   r.paph_k1 = pert(r.paph_k1, lam);
@@ -204,12 +204,12 @@ C2_HD void make_level_in(const RawLevel& cur, real_t paph_k, real_t paph_surf, L
 #endif
 template <bool PERT>
 C2_HD real_t tropopause(ConstsP c, LevelTabP tab, InPtrsP p, const LaneOff& o, GeomP g, real_t lam) {
-  real_t ztrpaus = 0.1;
+  real_t ztrpaus = RC(0.1);
   const int kb0 = g->kb0, kb1 = g->kb1, nproma = g->nproma;
   if (kb1 > kb0) {
     const real_t ptsphy = c->ptsphy;
-    const double* pt = p->t;
-    const double* pg = p->gt;
+    const real_t* pt = p->t;
+    const real_t* pg = p->gt;
     long long d = (long long)kb0 * nproma;
     real_t t0 = pt[o.full + d], g0 = pg[o.cml + d];
     if (PERT) { t0 = pert(t0, lam); g0 = pert(g0, lam); }
@@ -231,7 +231,7 @@ C2_HD real_t tropopause(ConstsP c, LevelTabP tab, InPtrsP p, const LaneOff& o, G
           if (PERT) { t1 = pert(t1, lam); g1 = pert(g1, lam); }
           const real_t tdn = t1 + ptsphy * g1;
           const real_t ce = tab->lev[jk].ceta;
-          if (ce > 0.1 && ce < 0.4 && tup > tdn) ztrpaus = ce;
+          if (ce > RC(0.1) && ce < RC(0.4) && tup > tdn) ztrpaus = ce;
           tup = tdn;
         }
       }
@@ -261,7 +261,7 @@ C2_HD void store_out(OutPtrsP pp, const LaneOffT<OT>& o, int nproma, int jk, con
 
 C2_HD void store_top(OutPtrsP p, const LaneOff& o, ConstsP c) {
   // fluxes at the model top are zero (cloudsc2.F90:308-309); enthalpy fluxes -0*RLVTT (:732-733)
-  const real_t z = 0.0;
+  const real_t z = RC(0.0);
   p->fplsl[o.half] = z;
   p->fplsn[o.half] = z;
   p->fhpsl[o.half] = -z * c->rlvtt;
@@ -290,7 +290,7 @@ enum : unsigned {
 // SATUR for one column
 // ---------------------------------------------------------------------------------------------------------
 struct SaturArgs {
-  Consts c; Geom g; Strides s; const double* pap; const double* t; double* qsat;
+  Consts c; Geom g; Strides s; const real_t* pap; const real_t* t; real_t* qsat;
 };
 typedef const C2_CONST_AS SaturArgs* SaturArgsP;
 
@@ -300,9 +300,9 @@ C2_HD void satur_column(long long gcol, SaturArgsP a) {
   if (!lane_setup(&a->g, &a->s, gcol, o, active)) return;
   if (!active) return;
   const int nlev = a->g.nlev, nproma = a->g.nproma;
-  const double* pap = a->pap;
-  const double* t = a->t;
-  double* qsat = a->qsat;
+  const real_t* pap = a->pap;
+  const real_t* t = a->t;
+  real_t* qsat = a->qsat;
   for (int jk = 0; jk < nlev; ++jk) {
     long long d = (long long)jk * nproma;
     stg(qsat, o.full + d, satur_point<P>(C2_CONSTS(a), ldg(pap, o.full + d), ldg(t, o.full + d)));
@@ -323,8 +323,8 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
   LaneOff o; bool active;
   if (!lane_setup(&a->g, &a->s, gcol, o, active)) return;
   const int nlev = a->g.nlev, nproma = a->g.nproma;
-  const real_t lam = PERT ? a->lam : 0.0;
-  double* zero_plane = a->zero_plane;
+  const real_t lam = PERT ? a->lam : RC(0.0);
+  real_t* zero_plane = a->zero_plane;
   long long ozero = 0;
   if (zero_plane) {
     long long ibl = gcol / nproma;
@@ -333,11 +333,11 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
   if (!active) {
     // padded tail of the last block: the driver zeroes the whole block's PCOVPTOT and CLD(:,:,NCLV)
     // (cloudsc_driver_mod.F90:87-88); nothing else is touched.
-    double* cov = a->out.covptot;
+    real_t* cov = a->out.covptot;
     for (int jk = 0; jk < nlev; ++jk) {
       long long d = (long long)jk * nproma;
-      cov[o.full + d] = 0.0;
-      if (zero_plane) zero_plane[ozero + d] = 0.0;
+      cov[o.full + d] = RC(0.0);
+      if (zero_plane) zero_plane[ozero + d] = RC(0.0);
     }
     return;
   }
@@ -345,14 +345,14 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
   ConstsP c = C2_CONSTS(a);
   InPtrsP in = &a->in;
   OutPtrsP out = &a->out;
-  double* ckpt = CKPT ? a->ckpt : nullptr;
+  real_t* ckpt = CKPT ? a->ckpt : nullptr;
   const long long osc = CKPT ? (gcol / nproma) * ((long long)nproma * nlev) + (gcol % nproma) : 0;
 
   real_t ztrpaus = tropopause<PERT>(c, tab, in, o, &a->g, lam);
   RhCrit rh;
   rhcrit_setup(ztrpaus, rh);
 
-  real_t paph_surf = 0.0;
+  real_t paph_surf = RC(0.0);
   if (EVAP) {
     paph_surf = in->paph[o.half + (long long)nlev * nproma];
     if (PERT) paph_surf = pert(paph_surf, lam);
@@ -360,7 +360,7 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
 
   store_top(out, o, c);
 
-  Carry cy; cy.rfl = 0.0; cy.sfl = 0.0; cy.covptot = 0.0;
+  Carry cy; cy.rfl = RC(0.0); cy.sfl = RC(0.0); cy.covptot = RC(0.0);
   real_t paph_k = in->paph[o.half];
   if (PERT) paph_k = pert(paph_k, lam);
   // offsets used inside the level loop, in the variant's offset type
@@ -390,9 +390,9 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
     {
       const real_t s1 = x.paph_k1 + x.pap + x.q + x.qs + x.t + x.l + x.i + x.lude;
       const real_t s2 = x.lu_k1 + x.mfu + x.mfd + x.gt + x.gq + x.gl + x.gi + x.supsat + cy.rfl;
-      cy.rfl = s1 * 1e-9 + s2 * 1e-9;
-      lo.tent = s1; lo.tenq = s2; lo.tenl = s1 + s2; lo.teni = s1 - s2; lo.clc = s1 * 0.5; lo.covptot = s2 * 0.5;
-      lo.fplsl = cy.rfl; lo.fplsn = s1 * 0.25; lo.fhpsl = s2 * 0.25; lo.fhpsn = s1 * 0.125;
+      cy.rfl = s1 * RC(1e-9) + s2 * RC(1e-9);
+      lo.tent = s1; lo.tenq = s2; lo.tenl = s1 + s2; lo.teni = s1 - s2; lo.clc = s1 * RC(0.5); lo.covptot = s2 * RC(0.5);
+      lo.fplsl = cy.rfl; lo.fplsn = s1 * RC(0.25); lo.fhpsl = s2 * RC(0.25); lo.fhpsn = s1 * RC(0.125);
       (void)tr; (void)k; (void)rh;
     }
 #else
@@ -400,7 +400,7 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
 #endif
     C2_LAUNDER(ap);
     store_out(&ap->out, ol, nproma, jk, lo);
-    if (zero_plane) stg(zero_plane, ozl + level_off(OT(), jk, nproma), 0.0);
+    if (zero_plane) stg(zero_plane, ozl + level_off(OT(), jk, nproma), RC(0.0));
     paph_k = cur.paph_k1;
   };
 
@@ -431,11 +431,11 @@ C2_HD void tl_column(long long gcol, TlArgsP a) {
   InPtrsP in = &a->in, din = &a->din;
   OutPtrsP out = &a->out, dout = &a->dout;
 
-  real_t ztrpaus = tropopause<false>(c, tab, in, o, &a->g, 0.0);
+  real_t ztrpaus = tropopause<false>(c, tab, in, o, &a->g, RC(0.0));
   RhCrit rh;
   rhcrit_setup(ztrpaus, rh);
 
-  real_t paph_surf = 0.0, dpaph_surf = 0.0;
+  real_t paph_surf = RC(0.0), dpaph_surf = RC(0.0);
   if (EVAP) {
     paph_surf = in->paph[o.half + (long long)nlev * nproma];
     dpaph_surf = din->paph[op.half + (long long)nlev * nproma];
@@ -444,8 +444,8 @@ C2_HD void tl_column(long long gcol, TlArgsP a) {
   if (STORE_TRAJ) store_top(out, o, c);
   store_top(dout, op, c);
 
-  Carry cy; cy.rfl = 0.0; cy.sfl = 0.0; cy.covptot = 0.0;
-  Carry dcy; dcy.rfl = 0.0; dcy.sfl = 0.0; dcy.covptot = 0.0;
+  Carry cy; cy.rfl = RC(0.0); cy.sfl = RC(0.0); cy.covptot = RC(0.0);
+  Carry dcy; dcy.rfl = RC(0.0); dcy.sfl = RC(0.0); dcy.covptot = RC(0.0);
   RawLevel cur, nxt, dcur, dnxt;
   real_t paph_k = in->paph[o.half], dpaph_k = din->paph[op.half];
   const LaneOffT<OT> ol = lane_off_as<OT>(o), opl = lane_off_as<OT>(op);  // offsets used inside the level loop
@@ -511,7 +511,7 @@ C2_HD void ad_load_level(AdArgsP ap, const LaneOffT<OT>& o, const LaneOffT<OT>& 
   {
     const InPtrs p = ap->nl.in;
     L.paph_k = ldg(p.paph, o.half + d);
-    L.cur.lu_k1 = last ? 0.0 : ldg(p.lu, o.full + d1);
+    L.cur.lu_k1 = last ? RC(0.0) : ldg(p.lu, o.full + d1);
     L.cur.pap = ldg(p.pap, o.full + d);
     L.cur.q = ldg(p.q, o.full + d);
     L.cur.t = ldg(p.t, o.full + d);
@@ -558,8 +558,8 @@ C2_HD void ad_load_level(AdArgsP ap, const LaneOffT<OT>& o, const LaneOffT<OT>& 
   L.xo.gq = ldg(px.gq, oa.cml + d);
   L.xo.gl = ldg(px.gl, oa.cml + d);
   L.xo.gi = ldg(px.gi, oa.cml + d);
-  L.xo.lu_k1 = last ? 0.0 : ldg(px.lu, oa.full + d1);
-  L.xo.paph_k1 = last ? 0.0 : ldg(px.paph, oa.half + d1);
+  L.xo.lu_k1 = last ? RC(0.0) : ldg(px.lu, oa.full + d1);
+  L.xo.paph_k1 = last ? RC(0.0) : ldg(px.paph, oa.half + d1);
 }
 
 // reverse sweep (cloudsc2ad.F90:877-1740); the trajectory pass has run before
@@ -583,15 +583,15 @@ C2_HD void ad_reverse_column(long long gcol, AdArgsP a) {
   const LaneOffT<OT> ol = lane_off_as<OT>(o), oa = lane_off_as<OT>(oa64);
   const OT osc = (OT)(osc64 * (OFF32 ? 8 : 1));
 
-  real_t ztrpaus = tropopause<false>(c, tab, in, o, &a->nl.g, 0.0);
+  real_t ztrpaus = tropopause<false>(c, tab, in, o, &a->nl.g, RC(0.0));
   RhCrit rh;
   rhcrit_setup(ztrpaus, rh);
   const real_t paph_bottom = in->paph[o.half + (long long)nlev * nproma];
-  const real_t paph_surf = EVAP ? paph_bottom : 0.0;
+  const real_t paph_surf = EVAP ? paph_bottom : RC(0.0);
 
-  Carry acy; acy.rfl = 0.0; acy.sfl = 0.0; acy.covptot = 0.0;
-  real_t paph_pending = 0.0;  // contribution of level jk+1 to the PAPHP1 adjoint at half level jk+1
-  real_t surf_acc = 0.0;      // PAPHP1(KLEV+1) adjoint, written once at the end
+  Carry acy; acy.rfl = RC(0.0); acy.sfl = RC(0.0); acy.covptot = RC(0.0);
+  real_t paph_pending = RC(0.0);  // contribution of level jk+1 to the PAPHP1 adjoint at half level jk+1
+  real_t surf_acc = RC(0.0);      // PAPHP1(KLEV+1) adjoint, written once at the end
   real_t paph_k1 = paph_bottom;
   AdLevelLoads L;
   for (int jk = nlev - 1; jk >= 0; --jk) {
@@ -648,16 +648,16 @@ C2_HD void ad_reverse_column(long long gcol, AdArgsP a) {
     paph_pending = ax.paph_k;
 
     // output adjoints are consumed (cloudsc2ad.F90:917-919,955-966,1173,1572)
-    stg(pa.tent, oa.loc + d, 0.0);
-    stg(pa.tenq, oa.loc + d, 0.0);
-    stg(pa.tenl, oa.loc + d, 0.0);
-    stg(pa.teni, oa.loc + d, 0.0);
-    stg(pa.clc, oa.full + d, 0.0);
-    stg(pa.covptot, oa.full + d, 0.0);
-    stg(pa.fplsl, oa.half + d1, 0.0);
-    stg(pa.fplsn, oa.half + d1, 0.0);
-    stg(pa.fhpsl, oa.half + d1, 0.0);
-    stg(pa.fhpsn, oa.half + d1, 0.0);
+    stg(pa.tent, oa.loc + d, RC(0.0));
+    stg(pa.tenq, oa.loc + d, RC(0.0));
+    stg(pa.tenl, oa.loc + d, RC(0.0));
+    stg(pa.teni, oa.loc + d, RC(0.0));
+    stg(pa.clc, oa.full + d, RC(0.0));
+    stg(pa.covptot, oa.full + d, RC(0.0));
+    stg(pa.fplsl, oa.half + d1, RC(0.0));
+    stg(pa.fplsn, oa.half + d1, RC(0.0));
+    stg(pa.fhpsl, oa.half + d1, RC(0.0));
+    stg(pa.fhpsn, oa.half + d1, RC(0.0));
 
     paph_k1 = L.paph_k;
   }
@@ -666,10 +666,10 @@ C2_HD void ad_reverse_column(long long gcol, AdArgsP a) {
   ain->paph[oa64.half] += paph_pending;
   ain->paph[oa64.half + (long long)nlev * nproma] += surf_acc;
   // the adjoint of the (constant zero) top fluxes is discarded (cloudsc2ad.F90:1678-1679,917-919)
-  aout->fplsl[oa64.half] = 0.0;
-  aout->fplsn[oa64.half] = 0.0;
-  aout->fhpsl[oa64.half] = 0.0;
-  aout->fhpsn[oa64.half] = 0.0;
+  aout->fplsl[oa64.half] = RC(0.0);
+  aout->fplsn[oa64.half] = RC(0.0);
+  aout->fhpsl[oa64.half] = RC(0.0);
+  aout->fhpsn[oa64.half] = RC(0.0);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -701,7 +701,7 @@ C2_HD double adjoint_norm1_column(int nlev, int nproma, const LaneOff& oa, const
 
 // norm2 = <x0, x_adj> with x0 = 0.01 * trajectory inputs; ZSUPSAT0 = 0 (:139,157) so that term vanishes
 C2_HD double adjoint_norm2_column(int nlev, int nproma, const LaneOff& o, const LaneOff& oa, long long oq, const InPtrs& in,
-                                  const double* qsat, const InPtrs& xa) {
+                                  const real_t* qsat, const InPtrs& xa) {
   double s_aph = 0, s_ap = 0, s_q = 0, s_qs = 0, s_t = 0, s_l = 0, s_i = 0, s_lude = 0, s_lu = 0, s_mfu = 0, s_mfd = 0, s_gt = 0,
          s_gq = 0, s_gl = 0, s_gi = 0;
   for (int jk = 0; jk <= nlev; ++jk) {
@@ -729,7 +729,7 @@ C2_HD double adjoint_norm2_column(int nlev, int nproma, const LaneOff& o, const 
 }
 
 C2_HD double adjoint_norm3(double n1, double n2) {
-  const double eps = 2.220446049250313e-16;  // EPSILON(1._8)
+  const double eps = sizeof(real_t) == 4 ? 1.1920928955078125e-07 : 2.220446049250313e-16;  // EPSILON(1._JPRB)
   if (n2 == 0.0) return fabs(n1 - n2) / eps;
   return fabs(n1 - n2) / eps / n2;
 }

@@ -200,8 +200,8 @@ C2_VARIANT_TABLE(g_ad_kernels, ad_kernel, AdArgs, 64, C2_AD_FUSED != 0 && !(F & 
 // field(jl, jk, jm, ibl) = table((start + ibl*NPROMA + jl) mod period, jk, jm) for active columns, 0 for the padded
 // tail of the last block (expand_mod.F90:283-296; `start`,`period` = get_offsets, :30-46).
 __global__ void __launch_bounds__(256)
-expand_kernel(const double* __restrict__ table, int klon, int period, long long start, int nlevx, int ndim, int nproma,
-              long long ngptot, long long nblocks, double* __restrict__ field, long long block_stride) {
+expand_kernel(const real_t* __restrict__ table, int klon, int period, long long start, int nlevx, int ndim, int nproma,
+              long long ngptot, long long nblocks, real_t* __restrict__ field, long long block_stride) {
   const long long per_block = (long long)nproma * nlevx * ndim;
   const long long total = per_block * nblocks;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
@@ -210,7 +210,7 @@ expand_kernel(const double* __restrict__ table, int klon, int period, long long 
     const int jl = (int)(r % nproma);
     const long long lev = r / nproma;  // jk + nlevx*jm
     const long long g = ibl * nproma + jl;
-    double v = 0.0;
+    real_t v = 0;
     if (g < ngptot) v = table[(start + g) % period + (long long)klon * lev];
     field[ibl * block_stride + r] = v;
   }
@@ -220,8 +220,8 @@ expand_kernel(const double* __restrict__ table, int klon, int period, long long 
 // blocks (padding included, like MINVAL(FIELD(:,:,B))), max |FIELD-REF|, sum |FIELD-REF|, sum |REF| over the active
 // columns.  part[5*blockIdx.x + {0..4}]; a second launch folds the partials in a fixed order (deterministic sums).
 __global__ void __launch_bounds__(256)
-validate_partial_kernel(const double* __restrict__ table, int klon, int period, long long start, int nlevx, int ndim,
-                        int nproma, long long ngptot, long long nblocks, const double* __restrict__ field,
+validate_partial_kernel(const real_t* __restrict__ table, int klon, int period, long long start, int nlevx, int ndim,
+                        int nproma, long long ngptot, long long nblocks, const real_t* __restrict__ field,
                         long long block_stride, double* __restrict__ part) {
   const long long per_block = (long long)nproma * nlevx * ndim;
   const long long total = per_block * nblocks;
@@ -300,7 +300,7 @@ __device__ __forceinline__ double wave_max(double v) {
 // ERROR_NORM sums (cloudsc_driver_tl_mod.F90:21-31): one thread block per NPROMA block, lanes stride the
 // block's active columns, per-lane level sums, wave shuffles, then one LDS stage.
 // sums[(ibl*10 + f)*2 + {0,1}] = { sum(F - F5), sum(TL*lambda) }.
-struct TenPtrs { const double* p[10]; long long stride[10]; int nlevx[10]; };
+struct TenPtrs { const real_t* p[10]; long long stride[10]; int nlevx[10]; };
 
 __global__ void __launch_bounds__(256) taylor_sums_kernel(int nproma, int nlev, int ngptot, TenPtrs f, TenPtrs f5, TenPtrs tl,
                                                           double lambda, double* sums) {
@@ -310,9 +310,9 @@ __global__ void __launch_bounds__(256) taylor_sums_kernel(int nproma, int nlev, 
   __shared__ double red[2][4];
   for (int fi = 0; fi < 10; ++fi) {
     double s0 = 0.0, s1 = 0.0;
-    const double* a = f.p[fi] + (long long)ibl * f.stride[fi];
-    const double* b = f5.p[fi] + (long long)ibl * f5.stride[fi];
-    const double* t = tl.p[fi] + (long long)ibl * tl.stride[fi];
+    const real_t* a = f.p[fi] + (long long)ibl * f.stride[fi];
+    const real_t* b = f5.p[fi] + (long long)ibl * f5.stride[fi];
+    const real_t* t = tl.p[fi] + (long long)ibl * tl.stride[fi];
     const int nl = f.nlevx[fi];
     for (int jl = threadIdx.x; jl < icend; jl += blockDim.x) {
       for (int jk = 0; jk < nl; ++jk) {
@@ -351,7 +351,7 @@ __global__ void __launch_bounds__(kBlock) adjoint_norm1_kernel(Geom g, Strides s
 }
 
 __global__ void __launch_bounds__(kBlock)
-adjoint_norm2_kernel(Geom g, Strides s, Strides sa, InPtrs in, const double* qsat, long long qsat_stride, InPtrs xa,
+adjoint_norm2_kernel(Geom g, Strides s, Strides sa, InPtrs in, const real_t* qsat, long long qsat_stride, InPtrs xa,
                      double* norms, long long ncols_pad, double* gmax) {
   long long gcol = global_column();
   LaneOff o, oa; bool active;
@@ -446,7 +446,7 @@ bool fits_off32(const Geom& g, int nproma, int nlev, std::initializer_list<long 
   static const bool allow32 = !(getenv("CLOUDSC2_OFF32") && atoi(getenv("CLOUDSC2_OFF32")) == 0);  // 0: measurements only
   const long long nb = g.ncols_pad / nproma;
   const long long span = std::max(strides) * nb + (long long)nproma * (nlev + 2);
-  return allow32 && span * 8 < (1LL << 32);
+  return allow32 && span * (long long)sizeof(real_t) < (1LL << 32);
 }
 
 inline unsigned grid_for(long long ncols, int block) { return (unsigned)((ncols + block - 1) / block); }
@@ -471,6 +471,7 @@ extern "C" {
 const char* cloudsc2_last_error(void) { return g_err.c_str(); }
 
 int cloudsc2_device_available(void) { return device_ok() ? 1 : 0; }
+int cloudsc2_real_bytes(void) { return (int)sizeof(cloudsc2_real); }
 
 void cloudsc2_set_math_mode(int precise) { g_precise.store(precise ? 1 : 0); }
 int cloudsc2_get_math_mode(void) { return g_precise.load(); }
@@ -597,7 +598,7 @@ int cloudsc2_tl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
 
 int cloudsc2_ad_launch(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
                        const cloudsc2_inputs* traj_in, const cloudsc2_outputs* traj_out,
-                       const cloudsc2_inputs* adj_in, const cloudsc2_outputs* adj_out, double* scratch,
+                       const cloudsc2_inputs* adj_in, const cloudsc2_outputs* adj_out, cloudsc2_real* scratch,
                        void* stream) {
   Geom g;
   int rc = check_geom(prm, nproma, nlev, ngptot, g);
@@ -639,7 +640,7 @@ int cloudsc2_ad_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
 // ---------------------------------------------------------------------------------------------------------
 // state expansion / validation launchers
 // ---------------------------------------------------------------------------------------------------------
-static int check_expand_args(const double* table, int klon, int period, long long start, int nlevx, int ndim, int nproma,
+static int check_expand_args(const cloudsc2_real* table, int klon, int period, long long start, int nlevx, int ndim, int nproma,
                              long long ngptot, cloudsc2_field field, long long* nblocks) {
   if (!device_ok()) return fail(CLOUDSC2_ENODEVICE, "no HIP device available (this library has no CPU path)");
   if (!table || !field.ptr) return fail(CLOUDSC2_EINVAL, "NULL argument");
@@ -651,7 +652,7 @@ static int check_expand_args(const double* table, int klon, int period, long lon
   return 0;
 }
 
-int cloudsc2_expand_launch(const double* table, int klon, int period, long long start, int nlevx, int ndim, int nproma,
+int cloudsc2_expand_launch(const cloudsc2_real* table, int klon, int period, long long start, int nlevx, int ndim, int nproma,
                            long long ngptot, cloudsc2_field field, void* stream) {
   long long nblocks;
   int rc = check_expand_args(table, klon, period, start, nlevx, ndim, nproma, ngptot, field, &nblocks);
@@ -666,7 +667,7 @@ int cloudsc2_expand_launch(const double* table, int klon, int period, long long 
 
 int cloudsc2_validate_workspace_doubles(void) { return 5 * 2048; }
 
-int cloudsc2_validate_launch(const double* table, int klon, int period, long long start, int nlevx, int ndim, int nproma,
+int cloudsc2_validate_launch(const cloudsc2_real* table, int klon, int period, long long start, int nlevx, int ndim, int nproma,
                              long long ngptot, cloudsc2_field field, double* workspace, double* stats, void* stream) {
   long long nblocks;
   int rc = check_expand_args(table, klon, period, start, nlevx, ndim, nproma, ngptot, field, &nblocks);
@@ -675,7 +676,7 @@ int cloudsc2_validate_launch(const double* table, int klon, int period, long lon
   const long long total = nblocks * nproma * nlevx * ndim;
   const int nparts = (int)std::min<long long>((total + 255) / 256, 2048);
   hipLaunchKernelGGL(validate_partial_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, table, klon, period, start,
-                     nlevx, ndim, nproma, ngptot, nblocks, (const double*)field.ptr, field.block_stride, workspace);
+                     nlevx, ndim, nproma, ngptot, nblocks, (const real_t*)field.ptr, field.block_stride, workspace);
   hipLaunchKernelGGL(validate_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double*)workspace, nparts, stats);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -734,7 +735,7 @@ int cloudsc2_adjoint_norms_launch(int nproma, int nlev, int ngptot, const clouds
     InPtrs ip, xp;
     if ((rc = resolve_in(*traj_in, false, s, ip))) return rc;
     if ((rc = resolve_in(*x_adj, true, sa, xp))) return rc;
-    hipLaunchKernelGGL(adjoint_norm2_kernel, grid, block, 0, (hipStream_t)stream, g, s, sa, ip, (const double*)qsat->ptr,
+    hipLaunchKernelGGL(adjoint_norm2_kernel, grid, block, 0, (hipStream_t)stream, g, s, sa, ip, (const real_t*)qsat->ptr,
                        qsat->block_stride, xp, norms, g.ncols_pad, blockmax);
     HIP_TRY(hipGetLastError());
   }
@@ -753,7 +754,7 @@ void cloudsc2_expand_offsets(int klon, long long ngptot, long long ngptotg, int 
 
 double cloudsc2_validate_relerr(double esum, double rsum, int* iopt, int* warn) {
   // validate_mod.F90:272-289
-  const double zeps = 2.220446049250313e-16;
+  const double zeps = sizeof(real_t) == 4 ? 1.1920928955078125e-07 : 2.220446049250313e-16;  // EPSILON(1.0_JPRB)
   double zrel; int io;
   if (esum < zeps) { zrel = 0.0; io = 1; }
   else if (rsum < zeps) { zrel = esum / (1.0 + rsum); io = 2; }

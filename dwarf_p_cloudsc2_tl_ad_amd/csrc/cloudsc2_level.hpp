@@ -20,11 +20,18 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <cmath>
 #include "../../include/cloudsc2_hip.h"
 
 namespace cloudsc2 {
 
-typedef double real_t;
+// JPRB (src/common/module/parkind1.F90:40-44): fp64, or fp32 when the library is built with -DCLOUDSC2_SINGLE (the
+// reference's -DSINGLE).  Every literal of the column code is written RC(x) so that no fp32 expression is promoted.
+typedef cloudsc2_real real_t;
+#define RC(x) ((real_t)(x))
+// <cmath>'s overload sets, so that the same call is the fp32 or the fp64 function
+using std::cosh; using std::exp; using std::fabs; using std::fma; using std::fmax; using std::fmin; using std::ldexp;
+using std::pow; using std::sqrt; using std::tanh;
 
 #define C2_HD __host__ __device__ __forceinline__
 
@@ -48,6 +55,15 @@ typedef double real_t;
 // shared / batch-inverted (Montgomery) between quotients, exp is a 15-instruction branch-free kernel (c2_exp),
 // tanh comes from one exp.  Results differ from correctly rounded ones by a few ulp (parity tolerance: 1e-10).
 // ---------------------------------------------------------------------------------------------------------
+#if defined(CLOUDSC2_SINGLE)
+C2_HD real_t c2_rcp(real_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_rcpf(x);  // v_rcp_f32: 1 ulp
+#else
+  return 1.0f / x;
+#endif
+}
+#else
 C2_HD real_t c2_rcp(real_t x) {
 #if defined(__HIP_DEVICE_COMPILE__)
   // v_rcp_f64 is good to ~2^-23; one third-order step r(1 + e + e^2), e = 1 - x r, takes that to 2^-69 < 1/2 ulp
@@ -60,6 +76,8 @@ C2_HD real_t c2_rcp(real_t x) {
   return 1.0 / x;
 #endif
 }
+
+#endif
 
 C2_HD void c2_rcp2(real_t a, real_t b, real_t& ra, real_t& rb) {
   real_t r = c2_rcp(a * b);
@@ -84,6 +102,27 @@ C2_HD real_t quot(real_t num, real_t den, real_t rden) { return PRECISE ? num / 
 template <bool PRECISE>
 C2_HD real_t recip(real_t den) { return PRECISE ? 1.0 / den : c2_rcp(den); }
 
+#if defined(CLOUDSC2_SINGLE)
+// fp32 exp: n = round(x log2 e) by the 1.5*2^23 trick, two-constant Cody-Waite reduction (the high part of ln2 has 9
+// trailing zero bits, so n*ln2_hi is exact for |n| < 512), degree-6 near-minimax polynomial on |r| <= ln2/2 (1e-8), v_ldexp_f32.
+C2_HD real_t c2_exp(real_t x) {
+  const float log2e = 1.44269502e+00f, ln2_hi = 6.93145752e-01f, ln2_lo = 1.42860677e-06f;
+  const float magic = 12582912.0f;  // 1.5 * 2^23
+  x = fmaxf(x, -200.0f);            // exp(-200) underflows to 0 in fp32 like exp(-inf)
+  const float nb = fmaf(x, log2e, magic);
+  const float n = nb - magic;
+  float r = fmaf(-n, ln2_hi, x);
+  r = fmaf(-n, ln2_lo, r);
+  float p = 1.393365208e-03f;
+  p = fmaf(p, r, 8.363181725e-03f);
+  p = fmaf(p, r, 4.166646674e-02f);
+  p = fmaf(p, r, 1.666657627e-01f);
+  p = fmaf(p, r, 5.0e-01f);
+  p = fmaf(p, r, 1.0f);
+  p = fmaf(p, r, 1.0f);
+  return ldexpf(p, (int)n);
+}
+#else
 // exp: n = round(x log2 e) by the 1.5*2^52 trick (the low dword of the biased sum IS the integer n, no convert),
 // r = x - n ln2 in one fma (ln2 rounded once: the error n*7.6e-17 stays below 3e-15 for |x| < 60, 2.4e-14 at the
 // underflow end), degree-10 near-minimax polynomial on |r| <= ln2/2 (3.3e-16), one v_ldexp_f64: 15 instructions.
@@ -107,6 +146,7 @@ C2_HD real_t c2_exp(real_t x) {
   p = fma(p, r, 1.0);
   return ldexp(p, (int)(unsigned)__builtin_bit_cast(unsigned long long, nb));
 }
+#endif
 
 struct StageBlock { real_t v[8]; };
 // k0: first guess, entry reciprocals, stage A (saturation pressure)
@@ -166,7 +206,7 @@ inline void fill_stage_blocks(Consts& c) {
   k[K2_ZLFDCP0_R] = c.zlfdcp0_r; k[K2_ZMELTP2] = c.zmeltp2; k[K2_ZCONS2_R] = c.zcons2_r; k[K2_RG] = c.rg;
   k = c.k6.v; k[K6_ZLVDCP0] = c.rlvtt * c.zzz0; k[K6_ZLSDCP0] = c.rlstt * c.zzz0; k[K6_ZLFDCP0] = c.rlmlt * c.zzz0;
   k[K6_SPARE0] = c.zzz0;
-  k[K6_SPARE1] = k[K6_SPARE2] = k[K6_SPARE3] = k[K6_SPARE4] = 0.0;
+  k[K6_SPARE1] = k[K6_SPARE2] = k[K6_SPARE3] = k[K6_SPARE4] = RC(0.0);
   k = c.k3.v; k[K3_ZLCRIT_L_R] = c.zlcrit_l_r; k[K3_ZCKCODTL] = c.zckcodtl; k[K3_ZLCRIT_I_R] = c.zlcrit_i_r;
   k[K3_ZCKCODTI] = c.zckcodti; k[K3_RTT] = c.rtt; k[K3_ZCONS2] = c.zcons2; k[K3_ZLCRIT_L] = c.zlcrit_l;
   k[K3_ZLCRIT_I] = c.zlcrit_i;
@@ -176,7 +216,7 @@ inline void fill_stage_blocks(Consts& c) {
   k[K5_RALSDCP] = c.ralsdcp; k[K5_ZCONS2] = c.zcons2; k[K5_ZQTMST] = c.zqtmst; k[K5_RLVTT] = c.rlvtt;
   k[K5_RLSTT] = c.rlstt;
   k = c.ks.v; k[KS_R4LES] = c.r4les; k[KS_R4IES] = c.r4ies; k[KS_RTT] = c.rtt; k[KS_R3LES] = c.r3les;
-  k[KS_R3IES] = c.r3ies; k[KS_R2ES] = c.r2es; k[KS_RETV] = c.retv; k[KS_SPARE] = 0.0;
+  k[KS_R3IES] = c.r3ies; k[KS_R2ES] = c.r2es; k[KS_RETV] = c.retv; k[KS_SPARE] = RC(0.0);
   k = c.kt0.v; k[KT0_PTSPHY] = c.ptsphy; k[KT0_RTT] = c.rtt; k[KT0_R3IES] = c.r3ies; k[KT0_R4IES] = c.r4ies;
   k[KT0_R3LES] = c.r3les; k[KT0_R4LES] = c.r4les; k[KT0_R5LES] = c.r5les; k[KT0_R5IES] = c.r5ies;
   k = c.kt1.v; k[KT1_RETV] = c.retv; k[KT1_ZCONS3] = c.zcons3; k[KT1_RG] = c.rg; k[KT1_ZQTMST] = c.zqtmst;
@@ -184,9 +224,9 @@ inline void fill_stage_blocks(Consts& c) {
   k[KT1_ZLCRIT_I_R2] = c.zlcrit_i_r * c.zlcrit_i_r;
   // regularised autoconversion coefficients (cloudsc2tl.F90:754-760,794-800)
   k = c.kt2.v; k[KT2_CK_L] = c.lregcl ? c.zckcodtla : c.zckcodtl; k[KT2_CK_I] = c.lregcl ? c.zckcodtia : c.zckcodti;
-  k[KT2_RLVTT] = c.rlvtt; k[KT2_RLSTT] = c.rlstt; k[KT2_SPARE0] = k[KT2_SPARE1] = k[KT2_SPARE2] = k[KT2_SPARE3] = 0.0;
+  k[KT2_RLVTT] = c.rlvtt; k[KT2_RLSTT] = c.rlstt; k[KT2_SPARE0] = k[KT2_SPARE1] = k[KT2_SPARE2] = k[KT2_SPARE3] = RC(0.0);
   k = c.kf.v; k[KF_RTICE] = c.rtice; k[KF_RTWAT] = c.rtwat; k[KF_RTWAT_RTICE_R] = c.rtwat_rtice_r;
-  k[KF_SPARE0] = k[KF_SPARE1] = k[KF_SPARE2] = k[KF_SPARE3] = k[KF_SPARE4] = 0.0;
+  k[KF_SPARE0] = k[KF_SPARE1] = k[KF_SPARE2] = k[KF_SPARE3] = k[KF_SPARE4] = RC(0.0);
 }
 
 // host side: everything the kernels need besides fields and level tables, from the caller's parameter block
@@ -201,25 +241,25 @@ inline Consts make_consts(const cloudsc2_params& p, double ptsphy) {
   c.rlmin = p.rlmin; c.rpecons = p.rpecons; c.rlptrc = p.rlptrc;
   c.ptsphy = ptsphy;
   // cloudsc2.F90:235-240, cloudsc2tl.F90:321-328
-  c.zckcodtl = 2.0 * p.rkconv * ptsphy;
-  c.zckcodti = 5.0 * p.rkconv * ptsphy;
-  c.zckcodtla = c.zckcodtl / 100.0;
-  c.zckcodtia = c.zckcodti / 100.0;
-  c.zcons2 = 1.0 / (ptsphy * p.rg);
+  c.zckcodtl = RC(2.0) * p.rkconv * ptsphy;
+  c.zckcodti = RC(5.0) * p.rkconv * ptsphy;
+  c.zckcodtla = c.zckcodtl / RC(100.0);
+  c.zckcodtia = c.zckcodti / RC(100.0);
+  c.zcons2 = RC(1.0) / (ptsphy * p.rg);
   c.zcons3 = p.rlvtt / p.rcpd;
-  c.zmeltp2 = p.rtt + 2.0;
-  c.zqtmst = 1.0 / ptsphy;
+  c.zmeltp2 = p.rtt + RC(2.0);
+  c.zqtmst = RC(1.0) / ptsphy;
   c.evap = (p.levapls2 || p.ldrain1d) ? 1 : 0;
   // cloudsc2.F90:505-509,522-526
-  c.zlcrit_l = c.evap ? 1.9 * p.rclcrit : p.rclcrit * 2.0;
-  c.zlcrit_i = c.evap ? 1.e-04 : p.rclcrit * 2.0;
-  c.rcpd_r = 1.0 / p.rcpd;
-  c.zlcrit_l_r = 1.0 / c.zlcrit_l;
-  c.zlcrit_i_r = 1.0 / c.zlcrit_i;
+  c.zlcrit_l = c.evap ? RC(1.9) * p.rclcrit : p.rclcrit * RC(2.0);
+  c.zlcrit_i = c.evap ? RC(1.e-04) : p.rclcrit * RC(2.0);
+  c.rcpd_r = RC(1.0) / p.rcpd;
+  c.zlcrit_l_r = RC(1.0) / c.zlcrit_l;
+  c.zlcrit_i_r = RC(1.0) / c.zlcrit_i;
   c.zcons2_r = ptsphy * p.rg;
-  c.rvtmp2_zero = (p.rvtmp2 == 0.0) ? 1 : 0;
-  c.zzz0 = 1.0 / (p.rcpd + p.rcpd * p.rvtmp2 * 0.0);
-  c.zlfdcp0_r = 1.0 / (p.rlmlt * c.zzz0);
+  c.rvtmp2_zero = (p.rvtmp2 == RC(0.0)) ? 1 : 0;
+  c.zzz0 = RC(1.0) / (p.rcpd + p.rcpd * p.rvtmp2 * RC(0.0));
+  c.zlfdcp0_r = RC(1.0) / (p.rlmlt * c.zzz0);
   c.lregcl = p.lregcl ? 1 : 0;
   c.nlev = p.nlev;
   fill_stage_blocks(c);
@@ -302,24 +342,24 @@ struct RhCrit {
 
 C2_HD void rhcrit_setup(real_t ztrpaus, RhCrit& r) {
   r.zeta3 = ztrpaus;
-  real_t d = ztrpaus - 0.25;
-  real_t dq = d / 0.15;
-  r.zrh2 = 0.35 + 0.14 * (dq * dq) + 0.04 * fmin(d, 0.0) / 0.15;
-  r.zdeta1 = 0.09 + 0.16 * (0.4 - ztrpaus) / 0.3;
+  real_t d = ztrpaus - RC(0.25);
+  real_t dq = d / RC(0.15);
+  r.zrh2 = RC(0.35) + RC(0.14) * (dq * dq) + RC(0.04) * fmin(d, RC(0.0)) / RC(0.15);
+  r.zdeta1 = RC(0.09) + RC(0.16) * (RC(0.4) - ztrpaus) / RC(0.3);
 }
 
 C2_HD real_t rhcrit_level(const RhCrit& r, real_t ceta) {
   // cloudsc2.F90:391-399 (ZRH1 = ZRH3 = 1, ZDETA2 = 0.3)
-  const real_t zdeta2 = 0.3;
-  real_t zcrh2 = 1.0;
+  const real_t zdeta2 = RC(0.3);
+  real_t zcrh2 = RC(1.0);
   if (ceta < r.zeta3) {
-    zcrh2 = 1.0;
+    zcrh2 = RC(1.0);
   } else if (ceta < (r.zeta3 + zdeta2)) {
-    zcrh2 = 1.0 + (r.zrh2 - 1.0) * ((ceta - r.zeta3) / zdeta2);
-  } else if (ceta < (1.0 - r.zdeta1)) {
+    zcrh2 = RC(1.0) + (r.zrh2 - RC(1.0)) * ((ceta - r.zeta3) / zdeta2);
+  } else if (ceta < (RC(1.0) - r.zdeta1)) {
     zcrh2 = r.zrh2;
   } else {
-    zcrh2 = 1.0 + (r.zrh2 - 1.0) * sqrt((1.0 - ceta) / r.zdeta1);
+    zcrh2 = RC(1.0) + (r.zrh2 - RC(1.0)) * sqrt((RC(1.0) - ceta) / r.zdeta1);
   }
   return zcrh2;
 }
@@ -330,7 +370,7 @@ C2_HD real_t ex(real_t x) { return PRECISE ? exp(x) : c2_exp(x); }
 // FOEALFA (src/common/include/fcttre.func.h:74-75)
 C2_HD real_t foealfa(ConstsP c, real_t t) {
   real_t x = (fmax(c->rtice, fmin(c->rtwat, t)) - c->rtice) * c->rtwat_rtice_r;
-  return fmin(1.0, x * x);
+  return fmin(RC(1.0), x * x);
 }
 
 // SATUR, LDPHYLIN branch (src/cloudsc2_nl/satur.F90:106-123)
@@ -341,7 +381,7 @@ C2_HD real_t satur_point(ConstsP c, real_t pap, real_t t) {
   real_t zalfa;
   {  // FOEALFA (fcttre.func.h:74-75)
     real_t xa = (fmax(kf.v[KF_RTICE], fmin(kf.v[KF_RTWAT], t)) - kf.v[KF_RTICE]) * kf.v[KF_RTWAT_RTICE_R];
-    zalfa = fmin(1.0, xa * xa);
+    zalfa = fmin(RC(1.0), xa * xa);
   }
   const real_t r4les = ks.v[KS_R4LES], r4ies = ks.v[KS_R4IES], rtt = ks.v[KS_RTT], r3les = ks.v[KS_R3LES],
                r3ies = ks.v[KS_R3IES], r2es = ks.v[KS_R2ES], retv = ks.v[KS_RETV];
@@ -349,10 +389,10 @@ C2_HD real_t satur_point(ConstsP c, real_t pap, real_t t) {
   if (P) {
     zfoeewl = r2es * exp(r3les * (t - rtt) / (t - r4les));
     zfoeewi = r2es * exp(r3ies * (t - rtt) / (t - r4ies));
-    real_t zfoeew = zalfa * zfoeewl + (1.0 - zalfa) * zfoeewi;
+    real_t zfoeew = zalfa * zfoeewl + (RC(1.0) - zalfa) * zfoeewi;
     zqs = zfoeew / pap;
-    if (zqs > 0.5) zqs = 0.5;
-    zcor = 1.0 / (1.0 - retv * zqs);
+    if (zqs > RC(0.5)) zqs = RC(0.5);
+    zcor = RC(1.0) / (RC(1.0) - retv * zqs);
   } else {
     real_t rl, ri, rp;
     c2_rcp3(t - r4les, t - r4ies, pap, rl, ri, rp);
@@ -361,10 +401,10 @@ C2_HD real_t satur_point(ConstsP c, real_t pap, real_t t) {
     // re-fetched inside every branch) than the ~20 instructions it saves
     zfoeewl = r2es * c2_exp(r3les * dt * rl);
     zfoeewi = r2es * c2_exp(r3ies * dt * ri);
-    real_t zfoeew = zalfa * zfoeewl + (1.0 - zalfa) * zfoeewi;
+    real_t zfoeew = zalfa * zfoeewl + (RC(1.0) - zalfa) * zfoeewi;
     zqs = zfoeew * rp;
-    if (zqs > 0.5) zqs = 0.5;
-    zcor = c2_rcp(1.0 - retv * zqs);
+    if (zqs > RC(0.5)) zqs = RC(0.5);
+    zcor = c2_rcp(RC(1.0) - retv * zqs);
   }
   return zqs * zcor;
 }
@@ -432,7 +472,7 @@ struct LevelTraj {
 template <bool P, bool EVAP>
 C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const LevelIn& x, Carry& cy,
                          LevelTraj& t, LevelOut& o) {
-  const real_t zqmax = 0.5, zeps2 = 1.e-10;
+  const real_t zqmax = RC(0.5), zeps2 = RC(1.e-10);
   const int rvtmp2_zero = c->rvtmp2_zero;
   const bool evap = EVAP;
 
@@ -451,12 +491,12 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
   // reciprocals known at level entry: 1/(T-R4LES), 1/(T-R4IES), 1/p, 1/dp from ONE v_rcp_f64
   t.tm4l = t.ztp2 - k0.v[K0_R4LES];
   t.tm4i = t.ztp2 - k0.v[K0_R4IES];
-  real_t rl = 0.0, ri = 0.0, rp, rdp;
+  real_t rl = RC(0.0), ri = RC(0.0), rp, rdp;
   if (P) {
-    rp = 1.0 / x.pap;
-    rdp = 1.0 / t.zdp;
-    rl = 1.0 / t.tm4l;  // TL/AD only
-    ri = 1.0 / t.tm4i;
+    rp = RC(1.0) / x.pap;
+    rdp = RC(1.0) / t.zdp;
+    rl = RC(1.0) / t.tm4l;  // TL/AD only
+    ri = RC(1.0) / t.tm4i;
   } else {
     real_t li = t.tm4l * t.tm4i;
     real_t pd = x.pap * t.zdp;
@@ -477,24 +517,24 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
   {
     real_t z3es, z4es, r4;
     if (P) {
-      real_t u = 0.17 * (t.ztp2 - k0.v[K0_RLPTRC]);
+      real_t u = RC(0.17) * (t.ztp2 - k0.v[K0_RLPTRC]);
       real_t ch = cosh(u);  // TL/AD only
-      t.zcosh2r = 1.0 / (ch * ch);
-      real_t zoealfaw = 0.545 * (tanh(u) + 1.0);
+      t.zcosh2r = RC(1.0) / (ch * ch);
+      real_t zoealfaw = RC(0.545) * (tanh(u) + RC(1.0));
       if (t.cold) { t.zfwat = zoealfaw; z3es = k0.v[K0_R3IES]; z4es = k0.v[K0_R4IES]; }
-      else        { t.zfwat = 1.0;      z3es = k0.v[K0_R3LES]; z4es = k0.v[K0_R4LES]; }
-      r4 = 0.0;
+      else        { t.zfwat = RC(1.0);      z3es = k0.v[K0_R3LES]; z4es = k0.v[K0_R4LES]; }
+      r4 = RC(0.0);
     } else if (t.cold) {
       // tanh(u)+1 = 2 e^{2u}/(e^{2u}+1),  1/cosh^2(u) = 4 e^{2u}/(e^{2u}+1)^2,  u = 0.17 (T - RLPTRC)
-      real_t e2 = c2_exp(0.34 * (t.ztp2 - k0.v[K0_RLPTRC]));
-      real_t re = c2_rcp(e2 + 1.0);
-      real_t th1 = 2.0 * e2 * re;
-      t.zcosh2r = 2.0 * th1 * re;
-      t.zfwat = 0.545 * th1;
+      real_t e2 = c2_exp(RC(0.34) * (t.ztp2 - k0.v[K0_RLPTRC]));
+      real_t re = c2_rcp(e2 + RC(1.0));
+      real_t th1 = RC(2.0) * e2 * re;
+      t.zcosh2r = RC(2.0) * th1 * re;
+      t.zfwat = RC(0.545) * th1;
       z3es = k0.v[K0_R3IES]; z4es = k0.v[K0_R4IES]; r4 = ri;
     } else {
-      t.zcosh2r = 0.0;  // only read when cold
-      t.zfwat = 1.0;
+      t.zcosh2r = RC(0.0);  // only read when cold
+      t.zfwat = RC(1.0);
       z3es = k0.v[K0_R3LES]; z4es = k0.v[K0_R4LES]; r4 = rl;
     }
     t.zfoeew = k0.v[K0_R2ES] * ex<P>(quot<P>(z3es * (t.ztp2 - rtt), t.ztp2 - z4es, r4));
@@ -507,19 +547,19 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
     t.zesdp = t.esdp_clip ? zqmax : zesdp1;
     t.zfacw = quot<P>(k1.v[K1_R5LES], t.tm4l * t.tm4l, rl * rl);
     t.zfaci = quot<P>(k1.v[K1_R5IES], t.tm4i * t.tm4i, ri * ri);
-    t.zfac = t.zfwat * t.zfacw + (1.0 - t.zfwat) * t.zfaci;
+    t.zfac = t.zfwat * t.zfacw + (RC(1.0) - t.zfwat) * t.zfaci;
     t.rdt = k1.v[K1_RD] * t.ztp2;
     if (P) {
-      t.zcor = 1.0 / (1.0 - retv * t.zesdp);
-      t.zfac1 = 1.0 / t.rdt;
-      t.zfac2 = 1.0 / (x.pap - retv * t.zfoeew);
+      t.zcor = RC(1.0) / (RC(1.0) - retv * t.zesdp);
+      t.zfac1 = RC(1.0) / t.rdt;
+      t.zfac2 = RC(1.0) / (x.pap - retv * t.zfoeew);
     } else {
       // 1/(1-RETV*esdp), 1/(RD*T), 1/(p-RETV*es) share one reciprocal (used in A and E)
-      c2_rcp3(1.0 - retv * t.zesdp, t.rdt, x.pap - retv * t.zfoeew, t.zcor, t.zfac1, t.zfac2);
+      c2_rcp3(RC(1.0) - retv * t.zesdp, t.rdt, x.pap - retv * t.zfoeew, t.zcor, t.zfac1, t.zfac2);
     }
     t.rtp2 = t.zfac1 * k1.v[K1_RD];  // 1/T (TL/AD only)
     t.zdqsdtemp = t.zfac * t.zcor * x.qs;
-    t.zcorqs = 1.0 + k1.v[K1_ZCONS3] * t.zdqsdtemp;
+    t.zcorqs = RC(1.0) + k1.v[K1_ZCONS3] * t.zdqsdtemp;
     t.qlim_is_qs = t.zqp2 > x.qs;
     t.zqlim = t.qlim_is_qs ? x.qs : t.zqp2;
   }
@@ -527,17 +567,17 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
   // B. critical relative humidity (cloudsc2.F90:384-407)
   t.zcrh2 = rhcrit_level(rh, k.ceta);
   t.below_rtice = t.ztp2 < k1.v[K1_RTICE];
-  t.zsupsat = t.below_rtice ? (1.8 - 3.e-03 * t.ztp2) : 1.0;
+  t.zsupsat = t.below_rtice ? (RC(1.8) - RC(3.e-03) * t.ztp2) : RC(1.0);
   t.zqsat = x.qs * t.zsupsat;
   t.zqcrit = t.zcrh2 * t.zqsat;
 
   // C. uniform-PDF cloud cover (cloudsc2.F90:413-426)
   t.zqt = t.zqp2 + t.zl + t.zi;
-  t.zqpd = 0.0; t.zqcd = 0.0; t.zden = 1.0; t.zsqrt = 1.0; t.rden = 1.0; t.rzsqrt = 1.0;
+  t.zqpd = RC(0.0); t.zqcd = RC(0.0); t.zden = RC(1.0); t.zsqrt = RC(1.0); t.rden = RC(1.0); t.rzsqrt = RC(1.0);
   if (t.zqt <= t.zqcrit) {
-    t.regime = 0; t.zclc = 0.0; t.zqc1 = 0.0;
+    t.regime = 0; t.zclc = RC(0.0); t.zqc1 = RC(0.0);
   } else if (t.zqt >= t.zqsat) {
-    t.regime = 1; t.zclc = 1.0; t.zqc1 = (1.0 - k.zscalm) * (t.zqsat - t.zqcrit);
+    t.regime = 1; t.zclc = RC(1.0); t.zqc1 = (RC(1.0) - k.zscalm) * (t.zqsat - t.zqcrit);
   } else {
     t.regime = 2;
     t.zqpd = t.zqsat - t.zqt;
@@ -546,19 +586,19 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
     t.rden = recip<P>(t.zden);
     t.zsqrt = sqrt(quot<P>(t.zqpd, t.zden, t.rden));
     t.rzsqrt = recip<P>(t.zsqrt);  // TL/AD only
-    t.zclc = 1.0 - t.zsqrt;
-    t.zqc1 = (k.zscalm * t.zqpd + (1.0 - k.zscalm) * t.zqcd) * (t.zclc * t.zclc);
+    t.zclc = RC(1.0) - t.zsqrt;
+    t.zqc1 = (k.zscalm * t.zqpd + (RC(1.0) - k.zscalm) * t.zqcd) * (t.zclc * t.zclc);
   }
 
   // D. convective component (cloudsc2.F90:432-443)
   t.zgdp = quot<P>(rg, x.paph_k1 - x.paph_k, rdp);
   t.zlude = x.lude * ptsphy * t.zgdp;
   t.llo1 = (!k.last) && (t.zlude >= k1.v[K1_RLMIN]) && (x.lu_k1 >= zeps2);
-  t.zexpl = 1.0; t.rlu = 0.0;
+  t.zexpl = RC(1.0); t.rlu = RC(0.0);
   if (t.llo1) {
     t.rlu = recip<P>(x.lu_k1);
     t.zexpl = ex<P>(quot<P>(-t.zlude, x.lu_k1, t.rlu));
-    t.clc = t.zclc + (1.0 - t.zclc) * (1.0 - t.zexpl);
+    t.clc = t.zclc + (RC(1.0) - t.zclc) * (RC(1.0) - t.zexpl);
     t.zqc2 = t.zqc1 + t.zlude;
   } else {
     t.clc = t.zclc;
@@ -581,11 +621,11 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
   // E. compensating subsidence (cloudsc2.F90:449-459)
   t.zrho = x.pap * t.zfac1;
   t.zrodqsdp = -t.zrho * x.qs * t.zfac2;
-  t.zldcp = t.zfwat * t.zlvdcp + (1.0 - t.zfwat) * t.zlsdcp;
-  t.zfac3 = recip<P>(1.0 + t.zldcp * t.zdqsdtemp);
+  t.zldcp = t.zfwat * t.zlvdcp + (RC(1.0) - t.zfwat) * t.zlsdcp;
+  t.zfac3 = recip<P>(RC(1.0) + t.zldcp * t.zdqsdtemp);
   t.dtdzmo = k2.v[K2_RG] * (k2.v[K2_RCPD_R] - t.zldcp * t.zrodqsdp) * t.zfac3;
   t.zdqsdz = t.zdqsdtemp * t.dtdzmo - k2.v[K2_RG] * t.zrodqsdp;
-  t.zfac4 = P ? 1.0 / t.zrho : t.rdt * rp;  // 1/rho
+  t.zfac4 = P ? RC(1.0) / t.zrho : t.rdt * rp;  // 1/rho
   {
     real_t xdq = t.zdqsdz * (x.mfu + x.mfd) * k2.v[K2_PTSPHY] * t.zfac4;
     t.llo3 = xdq < t.zqc2;
@@ -595,7 +635,7 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
 
   // F. condensate partition and condensation rates (cloudsc2.F90:465-468)
   t.zqlwc1 = t.zqc3 * t.zfwat;
-  t.zqiwc1 = t.zqc3 * (1.0 - t.zfwat);
+  t.zqiwc1 = t.zqc3 * (RC(1.0) - t.zfwat);
   t.zcondl1 = (t.zqlwc1 - t.zl) * k2.v[K2_ZQTMST];
   t.zcondi1 = (t.zqiwc1 - t.zi) * k2.v[K2_ZQTMST];
 
@@ -604,26 +644,26 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
   t.newmax = t.clc > cy.covptot;
   t.covptot1 = t.newmax ? t.clc : cy.covptot;
   t.covpclr1 = t.covptot1 - t.clc;
-  t.covpclr = (t.covpclr1 < 0.0) ? 0.0 : t.covpclr1;
+  t.covpclr = (t.covpclr1 < RC(0.0)) ? RC(0.0) : t.covpclr1;
 
   // H. melting of incoming snow (cloudsc2.F90:488-497)
   t.rfl_in = cy.rfl;
   t.sfl_in = cy.sfl;
-  t.melt = cy.sfl != 0.0;
+  t.melt = cy.sfl != RC(0.0);
   real_t rfln, sfln;
-  t.zcons = 1.0; t.rcons = 1.0; t.zz2s = 0.0; t.zsnmlt = 0.0; t.warm2 = 0; t.melt_all = 0;
+  t.zcons = RC(1.0); t.rcons = RC(1.0); t.zz2s = RC(0.0); t.zsnmlt = RC(0.0); t.warm2 = 0; t.melt_all = 0;
   if (t.melt) {
     const real_t zmeltp2 = k2.v[K2_ZMELTP2];
     if (P) t.zcons = k2.v[K2_ZCONS2] * t.zdp / t.zlfdcp;
     else t.zcons = k2.v[K2_ZCONS2] * t.zdp * t.rlfdcp;
-    t.warm2 = (t.ztp2 - zmeltp2) > 0.0;
-    t.zz2s = t.warm2 ? t.zcons * (t.ztp2 - zmeltp2) : 0.0;
+    t.warm2 = (t.ztp2 - zmeltp2) > RC(0.0);
+    t.zz2s = t.warm2 ? t.zcons * (t.ztp2 - zmeltp2) : RC(0.0);
     t.melt_all = cy.sfl <= t.zz2s;
     t.zsnmlt = t.melt_all ? cy.sfl : t.zz2s;
     rfln = cy.rfl + t.zsnmlt;
     sfln = cy.sfl - t.zsnmlt;
     // dT = -snmlt/zcons = -snmlt * ZLFDCP / (ZCONS2*dp)
-    t.rcons = P ? 1.0 / t.zcons : t.zlfdcp * (k2.v[K2_ZCONS2_R] * rdp);
+    t.rcons = P ? RC(1.0) / t.zcons : t.zlfdcp * (k2.v[K2_ZCONS2_R] * rdp);
     t.ztp1 = t.ztp2 - quot<P>(t.zsnmlt, t.zcons, t.rcons);
   } else {
     rfln = cy.rfl;
@@ -643,7 +683,7 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
     t.zcldl = quot<P>(t.zqlwc1, t.clc, t.rclc);
     real_t ql = quot<P>(t.zcldl, k3.v[K3_ZLCRIT_L], k3.v[K3_ZLCRIT_L_R]);
     t.zexp3 = ex<P>(-(ql * ql));
-    t.zdl = k3.v[K3_ZCKCODTL] * (1.0 - t.zexp3);
+    t.zdl = k3.v[K3_ZCKCODTL] * (RC(1.0) - t.zexp3);
     t.zexpdl = ex<P>(-t.zdl);
     real_t zlnew = t.clc * t.zcldl * t.zexpdl;
     t.zprr = t.zqlwc1 - zlnew;
@@ -651,17 +691,17 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
 
     t.zcldi = quot<P>(t.zqiwc1, t.clc, t.rclc);
     real_t qi = quot<P>(t.zcldi, k3.v[K3_ZLCRIT_I], k3.v[K3_ZLCRIT_I_R]);
-    t.zexp1 = ex<P>(0.025 * (t.ztp1 - rtt3));
+    t.zexp1 = ex<P>(RC(0.025) * (t.ztp1 - rtt3));
     t.zexp2 = ex<P>(-(qi * qi));
-    t.zdi = k3.v[K3_ZCKCODTI] * t.zexp1 * (1.0 - t.zexp2);
+    t.zdi = k3.v[K3_ZCKCODTI] * t.zexp1 * (RC(1.0) - t.zexp2);
     t.zexpdi = ex<P>(-t.zdi);
     real_t zinew = t.clc * t.zcldi * t.zexpdi;
     t.zprs = t.zqiwc1 - zinew;
     t.zqiwc = t.zqiwc1 - t.zprs;
   } else {
-    t.rclc = 0.0;
-    t.zcldl = 0.0; t.zexp3 = 1.0; t.zdl = 0.0; t.zexpdl = 1.0; t.zprr = 0.0; t.zqlwc = t.zqlwc1;
-    t.zcldi = 0.0; t.zexp1 = 1.0; t.zexp2 = 1.0; t.zdi = 0.0; t.zexpdi = 1.0; t.zprs = 0.0; t.zqiwc = t.zqiwc1;
+    t.rclc = RC(0.0);
+    t.zcldl = RC(0.0); t.zexp3 = RC(1.0); t.zdl = RC(0.0); t.zexpdl = RC(1.0); t.zprr = RC(0.0); t.zqlwc = t.zqlwc1;
+    t.zcldi = RC(0.0); t.zexp1 = RC(1.0); t.zexp2 = RC(1.0); t.zdi = RC(0.0); t.zexpdi = RC(1.0); t.zprs = RC(0.0); t.zqiwc = t.zqiwc1;
   }
 
   // ---- blocks k4 (first guess after the cloud processes, saturation adjustment) and k5 (adjustment, tendencies) ----
@@ -670,10 +710,10 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
   const real_t rtt4 = k4.v[K4_RTT], ptsphy4 = k4.v[K4_PTSPHY], retv4 = k4.v[K4_RETV], r2es4 = k4.v[K4_R2ES];
   t.zdr1 = zcons2dp * (t.zprr + t.zprs);
   t.frz1 = t.ztp1 < rtt4;
-  if (t.frz1) { t.zrfreeze1 = zcons2dp * t.zprr; t.zfwatr1 = 0.0; }
-  else        { t.zrfreeze1 = 0.0;               t.zfwatr1 = 1.0; }
+  if (t.frz1) { t.zrfreeze1 = zcons2dp * t.zprr; t.zfwatr1 = RC(0.0); }
+  else        { t.zrfreeze1 = RC(0.0);               t.zfwatr1 = RC(1.0); }
   rfln = rfln + t.zfwatr1 * t.zdr1;
-  sfln = sfln + (1.0 - t.zfwatr1) * t.zdr1;
+  sfln = sfln + (RC(1.0) - t.zfwatr1) * t.zdr1;
   t.rfln2 = rfln;
   t.sfln2 = sfln;
 
@@ -681,24 +721,24 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
   t.zprtot = rfln + sfln;
   t.llo2 = evap && (t.zprtot > zeps2) && (t.covpclr > zeps2);
   real_t covptot = t.covptot1;
-  real_t pcovptot = 0.0;
-  t.zevapr = 0.0; t.zevaps = 0.0;
+  real_t pcovptot = RC(0.0);
+  t.zevapr = RC(0.0); t.zevaps = RC(0.0);
   t.dpr_clip = 0; t.reset = 0;
-  t.zpreclr1 = 0.0; t.zqe = 0.0; t.zbeta = 0.0; t.zb = 0.0; t.zdtgdp = 1.0; t.zdpr1 = 0.0; t.zdpr = 0.0;
-  t.zpreclr = 0.0; t.omc = 1.0; t.zsqp = 1.0;
+  t.zpreclr1 = RC(0.0); t.zqe = RC(0.0); t.zbeta = RC(0.0); t.zb = RC(0.0); t.zdtgdp = RC(1.0); t.zdpr1 = RC(0.0); t.zdpr = RC(0.0);
+  t.zpreclr = RC(0.0); t.omc = RC(1.0); t.zsqp = RC(1.0);
   if (t.llo2) {
     t.zpreclr1 = t.zprtot * t.covpclr / t.covptot1;
-    t.omc = 1.0 - t.clc;
+    t.omc = RC(1.0) - t.clc;
     t.zqe = x.qs - (x.qs - t.zqlim) * t.covpclr / (t.omc * t.omc);
     t.zsqp = sqrt(x.pap / x.paph_surf);
-    t.zbeta = c->rg * c->rpecons * pow(t.zsqp / 5.09e-3 * t.zpreclr1 / t.covpclr, 0.5777);
-    t.zb = ptsphy4 * t.zbeta * (x.qs - t.zqe) / (1.0 + t.zbeta * ptsphy4 * t.zcorqs);
+    t.zbeta = c->rg * c->rpecons * pow(t.zsqp / RC(5.09e-3) * t.zpreclr1 / t.covpclr, RC(0.5777));
+    t.zb = ptsphy4 * t.zbeta * (x.qs - t.zqe) / (RC(1.0) + t.zbeta * ptsphy4 * t.zcorqs);
     t.zdtgdp = ptsphy4 * c->rg / (x.paph_k1 - x.paph_k);
     t.zdpr1 = t.covpclr * t.zb / t.zdtgdp;
     t.dpr_clip = t.zdpr1 > t.zpreclr1;
     t.zdpr = t.dpr_clip ? t.zpreclr1 : t.zdpr1;
     t.zpreclr = t.zpreclr1 - t.zdpr;
-    t.reset = t.zpreclr <= 0.0;
+    t.reset = t.zpreclr <= RC(0.0);
     if (t.reset) covptot = t.clc;
     pcovptot = covptot;
     t.zevapr = t.zdpr * t.rfln2 / t.zprtot;
@@ -708,7 +748,7 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
   }
 
   // K. first-guess T and q after the cloud processes (cloudsc2.F90:602-617)
-  const real_t w5 = t.zfwat * t.zlvdcp + (1.0 - t.zfwat) * t.zlsdcp;
+  const real_t w5 = t.zfwat * t.zlvdcp + (RC(1.0) - t.zfwat) * t.zlsdcp;
   const real_t ev = x.lude + t.zevapr + t.zevaps;
   const real_t lsv = t.zlsdcp - t.zlvdcp;
   {
@@ -733,17 +773,17 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
       t.a_tm4[it] = tt - t.z4es;
       real_t zcond1;
       if (P) {
-        t.a_rtm4[it] = 1.0 / t.a_tm4[it];
+        t.a_rtm4[it] = RC(1.0) / t.a_tm4[it];
         t.a_foeew[it] = r2es4 * exp(t.z3es * (tt - rtt4) / t.a_tm4[it]);
         real_t qs1 = t.zqp * t.a_foeew[it];
         t.a_clip[it] = qs1 > zqmax;
         if (t.a_clip[it]) qs1 = zqmax;
         t.a_qsatu[it] = qs1;
-        t.a_cor[it] = 1.0 / (1.0 - retv4 * qs1);
+        t.a_cor[it] = RC(1.0) / (RC(1.0) - retv4 * qs1);
         t.a_qsat[it] = qs1 * t.a_cor[it];
         t.a_z2s[it] = t.z5alcp / (t.a_tm4[it] * t.a_tm4[it]);
-        t.a_den[it] = 1.0 + t.a_qsat[it] * t.a_cor[it] * t.a_z2s[it];
-        t.a_rden[it] = 1.0 / t.a_den[it];
+        t.a_den[it] = RC(1.0) + t.a_qsat[it] * t.a_cor[it] * t.a_z2s[it];
+        t.a_rden[it] = RC(1.0) / t.a_den[it];
         zcond1 = (qq - t.a_qsat[it]) / t.a_den[it];
       } else {
         real_t r4 = c2_rcp(t.a_tm4[it]);
@@ -753,7 +793,7 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
         t.a_clip[it] = qs1 > zqmax;
         if (t.a_clip[it]) qs1 = zqmax;
         t.a_qsatu[it] = qs1;
-        real_t a = 1.0 - retv4 * qs1;
+        real_t a = RC(1.0) - retv4 * qs1;
         t.a_z2s[it] = t.z5alcp * (r4 * r4);
         real_t d = a * a + qs1 * t.a_z2s[it];
         real_t rd = c2_rcp(d);
@@ -761,7 +801,7 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
         // TL/AD coefficients (dead code in the NL kernel)
         t.a_cor[it] = c2_rcp(a);
         t.a_qsat[it] = qs1 * t.a_cor[it];
-        t.a_den[it] = 1.0 + t.a_qsat[it] * t.a_cor[it] * t.a_z2s[it];
+        t.a_den[it] = RC(1.0) + t.a_qsat[it] * t.a_cor[it] * t.a_z2s[it];
         t.a_rden[it] = (a * a) * rd;  // = 1/a_den
       }
       tt = tt + t.zaldcp * zcond1;
@@ -775,17 +815,17 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
   {
     const real_t zqtmst = k5.v[K5_ZQTMST];
     real_t d = t.zqpb - t.zqp1;
-    t.dq_pos = d >= 0.0;
-    t.zdq = t.dq_pos ? d : 0.0;
+    t.dq_pos = d >= RC(0.0);
+    t.zdq = t.dq_pos ? d : RC(0.0);
     t.zdr2 = k5.v[K5_ZCONS2] * t.zdp * t.zdq;
     t.frz2 = t.ztp3 < rtt4;
     real_t zrfreeze2;
-    if (t.frz2) { zrfreeze2 = t.zfwat * t.zdr2; t.zfwatr2 = 0.0; }
-    else        { zrfreeze2 = 0.0;              t.zfwatr2 = 1.0; }
+    if (t.frz2) { zrfreeze2 = t.zfwat * t.zdr2; t.zfwatr2 = RC(0.0); }
+    else        { zrfreeze2 = RC(0.0);              t.zfwatr2 = RC(1.0); }
     t.zcondl2 = t.zcondl1 + t.zfwatr2 * t.zdq * zqtmst;
-    t.zcondi2 = t.zcondi1 + (1.0 - t.zfwatr2) * t.zdq * zqtmst;
+    t.zcondi2 = t.zcondi1 + (RC(1.0) - t.zfwatr2) * t.zdq * zqtmst;
     rfln = rfln + t.zfwatr2 * t.zdr2;
-    sfln = sfln + (1.0 - t.zfwatr2) * t.zdr2;
+    sfln = sfln + (RC(1.0) - t.zfwatr2) * t.zdr2;
     t.zrfreeze3 = t.zrfreeze1 + zrfreeze2;
 
     o.tenq = -(t.zcondl2 + t.zcondi2) + ev * t.zgdp;
@@ -810,8 +850,8 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
 // Regularisation of the cloud-fraction perturbation (cloudsc2tl.F90:575-580, cloudsc2ad.F90:1554-1559)
 C2_HD real_t regcl_factor(real_t zqpd5, real_t zqcd5, real_t zscalm) {
   real_t zrat = zqpd5 * c2_rcp(zqcd5);
-  real_t w = 1.0 - zscalm * (1.0 - zrat);
-  return fmin(0.3, 3.5 * sqrt(zrat * (w * w * w)) * c2_rcp(1.0 - zscalm));
+  real_t w = RC(1.0) - zscalm * (RC(1.0) - zrat);
+  return fmin(RC(0.3), RC(3.5) * sqrt(zrat * (w * w * w)) * c2_rcp(RC(1.0) - zscalm));
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -837,7 +877,7 @@ C2_HD void level_tl(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
   real_t zl = dx.l + ptsphy * dx.gl;
   real_t zi = dx.i + ptsphy * dx.gi;
   real_t zdp = dx.paph_k1 - dx.paph_k;
-  real_t zlfdcp = 0.0, zlsdcp = 0.0, zlvdcp = 0.0;
+  real_t zlfdcp = RC(0.0), zlsdcp = RC(0.0), zlvdcp = RC(0.0);
   if (!rvtmp2_zero) {  // cloudsc2tl.F90:366-373
     real_t zzz = -c->rcpd * c->rvtmp2 * zqp1 * (t.zzz * t.zzz);
     zlfdcp = c->rlmlt * zzz; zlsdcp = c->rlstt * zzz; zlvdcp = c->rlvtt * zzz;
@@ -846,22 +886,22 @@ C2_HD void level_tl(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
   // A (cloudsc2tl.F90:463-501)
   // quotients of the reference are products with the trajectory's reciprocals (LevelTraj::rl, ri, zqp, rdp, ...)
   real_t zfwat, z3es, z4es, r4;
-  if (t.cold) { zfwat = 0.545 * 0.17 * ztp1 * t.zcosh2r; z3es = r3ies; z4es = r4ies; r4 = t.ri; }
-  else        { zfwat = 0.0;                            z3es = r3les; z4es = r4les; r4 = t.rl; }
+  if (t.cold) { zfwat = RC(0.545) * RC(0.17) * ztp1 * t.zcosh2r; z3es = r3ies; z4es = r4ies; r4 = t.ri; }
+  else        { zfwat = RC(0.0);                            z3es = r3les; z4es = r4les; r4 = t.rl; }
   const real_t rp = t.zqp;
   real_t zfoeew = z3es * (rtt - z4es) * ztp1 * t.zfoeew * (r4 * r4);
   real_t zesdp = zfoeew * rp - dx.pap * t.zfoeew * (rp * rp);
-  if (t.esdp_clip) zesdp = 0.0;
-  real_t zfacw = -2.0 * r5les * ztp1 * (t.rl * t.rl * t.rl);
-  real_t zfaci = -2.0 * r5ies * ztp1 * (t.ri * t.ri * t.ri);
-  real_t zfac = t.zfwat * zfacw + t.zfacw * zfwat + (1.0 - t.zfwat) * zfaci - t.zfaci * zfwat;
+  if (t.esdp_clip) zesdp = RC(0.0);
+  real_t zfacw = -RC(2.0) * r5les * ztp1 * (t.rl * t.rl * t.rl);
+  real_t zfaci = -RC(2.0) * r5ies * ztp1 * (t.ri * t.ri * t.ri);
+  real_t zfac = t.zfwat * zfacw + t.zfacw * zfwat + (RC(1.0) - t.zfwat) * zfaci - t.zfaci * zfwat;
   real_t zcor = retv * zesdp * (t.zcor * t.zcor);
   real_t zdqsdtemp = t.zfac * t.zcor * dx.qs + t.zfac * x.qs * zcor + t.zcor * x.qs * zfac;
   real_t zcorqs = zcons3 * zdqsdtemp;
   real_t zqlim = t.qlim_is_qs ? dx.qs : zqp1;
 
   // B (cloudsc2tl.F90:532-543)
-  real_t zsupsat = t.below_rtice ? (-3.e-03 * ztp1) : 0.0;
+  real_t zsupsat = t.below_rtice ? (-RC(3.e-03) * ztp1) : RC(0.0);
   real_t zqsat = dx.qs * t.zsupsat + x.qs * zsupsat;
   real_t zqcrit = t.zcrh2 * zqsat;
 
@@ -869,16 +909,16 @@ C2_HD void level_tl(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
   real_t zqt = zqp1 + zl + zi;
   real_t pclc, zqc;
   if (t.regime == 0) {
-    pclc = 0.0; zqc = 0.0;
+    pclc = RC(0.0); zqc = RC(0.0);
   } else if (t.regime == 1) {
-    pclc = 0.0; zqc = (1.0 - k.zscalm) * (zqsat - zqcrit);
+    pclc = RC(0.0); zqc = (RC(1.0) - k.zscalm) * (zqsat - zqcrit);
   } else {
     real_t zqpd = zqsat - zqt;
     real_t zqcd = zqsat - zqcrit;
-    pclc = -(0.5 * t.rzsqrt) * (zqpd * t.zden - t.zqpd * (zqcd - k.zscalm * (zqt - zqcrit))) * (t.rden * t.rden);
+    pclc = -(RC(0.5) * t.rzsqrt) * (zqpd * t.zden - t.zqpd * (zqcd - k.zscalm * (zqt - zqcrit))) * (t.rden * t.rden);
     if (lregcl) pclc = regcl_factor(t.zqpd, t.zqcd, k.zscalm) * pclc;
-    zqc = (k.zscalm * zqpd + (1.0 - k.zscalm) * zqcd) * (t.zclc * t.zclc) +
-          (k.zscalm * t.zqpd + (1.0 - k.zscalm) * t.zqcd) * 2.0 * t.zclc * pclc;
+    zqc = (k.zscalm * zqpd + (RC(1.0) - k.zscalm) * zqcd) * (t.zclc * t.zclc) +
+          (k.zscalm * t.zqpd + (RC(1.0) - k.zscalm) * t.zqcd) * RC(2.0) * t.zclc * pclc;
   }
 
   // D (cloudsc2tl.F90:595-622)
@@ -886,8 +926,8 @@ C2_HD void level_tl(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
   real_t zgdp = -rg * (dx.paph_k1 - dx.paph_k) * rdp2;
   real_t zlude = ptsphy * t.zgdp * dx.lude + ptsphy * x.lude * zgdp;
   if (t.llo1) {
-    pclc = pclc - pclc * (1.0 - t.zexpl) + ((1.0 - t.zclc) * t.rlu) * t.zexpl * zlude -
-           ((1.0 - t.zclc) * t.zlude * (t.rlu * t.rlu)) * t.zexpl * dx.lu_k1;
+    pclc = pclc - pclc * (RC(1.0) - t.zexpl) + ((RC(1.0) - t.zclc) * t.rlu) * t.zexpl * zlude -
+           ((RC(1.0) - t.zclc) * t.zlude * (t.rlu * t.rlu)) * t.zexpl * dx.lu_k1;
     zqc = zqc + zlude;
   }
 
@@ -895,14 +935,14 @@ C2_HD void level_tl(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
   {
     real_t zrho = (dx.pap - ztp1 * x.pap * t.rtp2) * t.zfac1;
     real_t zrodqsdp = (-zrho * x.qs - t.zrho * dx.qs + t.zrho * x.qs * (dx.pap - retv * zfoeew) * t.zfac2) * t.zfac2;
-    real_t zldcp = zfwat * t.zlvdcp + t.zfwat * zlvdcp + (1.0 - t.zfwat) * zlsdcp - zfwat * t.zlsdcp;
+    real_t zldcp = zfwat * t.zlvdcp + t.zfwat * zlvdcp + (RC(1.0) - t.zfwat) * zlsdcp - zfwat * t.zlsdcp;
     real_t dtdzmo = -(rg * (zldcp * t.zrodqsdp + t.zldcp * zrodqsdp) +
                       t.dtdzmo * (t.zldcp * zdqsdtemp + zldcp * t.zdqsdtemp)) * t.zfac3;
     real_t zdqsdz = t.zdqsdtemp * dtdzmo + zdqsdtemp * t.dtdzmo - rg * zrodqsdp;
     real_t zdqc;
     if (t.llo3) {
       zdqc = (ptsphy * (zdqsdz * (x.mfu + x.mfd) + t.zdqsdz * (dx.mfu + dx.mfd)) - t.zdqc * zrho) * t.zfac4;
-      if (lregcl) zdqc = zdqc * 0.1;
+      if (lregcl) zdqc = zdqc * RC(0.1);
     } else {
       zdqc = zqc;
     }
@@ -911,20 +951,20 @@ C2_HD void level_tl(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
 
   // F (cloudsc2tl.F90:670-680)
   real_t zqlwc = zqc * t.zfwat + t.zqc3 * zfwat;
-  real_t zqiwc = zqc * (1.0 - t.zfwat) - t.zqc3 * zfwat;
+  real_t zqiwc = zqc * (RC(1.0) - t.zfwat) - t.zqc3 * zfwat;
   real_t zcondl = (zqlwc - zl) * zqtmst;
   real_t zcondi = (zqiwc - zi) * zqtmst;
 
   // G (cloudsc2tl.F90:687-696)
   real_t zcovptot = t.newmax ? pclc : dcy.covptot;
   real_t zcovpclr = zcovptot - pclc;
-  if (t.covpclr1 < 0.0) zcovpclr = 0.0;
+  if (t.covpclr1 < RC(0.0)) zcovpclr = RC(0.0);
 
   // H (cloudsc2tl.F90:704-733)
   real_t zrfln, zsfln;
   if (t.melt) {
     real_t zcons = zcons2 * (zdp * t.zlfdcp - t.zdp * zlfdcp) * (t.rlfdcp * t.rlfdcp);
-    real_t zz2s = t.warm2 ? (t.zcons * ztp1 + zcons * (t.ztp2 - zmeltp2)) : 0.0;
+    real_t zz2s = t.warm2 ? (t.zcons * ztp1 + zcons * (t.ztp2 - zmeltp2)) : RC(0.0);
     real_t zsnmlt = t.melt_all ? dcy.sfl : zz2s;
     zrfln = dcy.rfl + zsnmlt;
     zsfln = dcy.sfl - zsnmlt;
@@ -935,12 +975,12 @@ C2_HD void level_tl(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
   }
 
   // I (cloudsc2tl.F90:739-840)
-  real_t zprr = 0.0, zprs = 0.0;
+  real_t zprr = RC(0.0), zprs = RC(0.0);
   if (t.cloudy) {
     const real_t rclc2 = t.rclc * t.rclc;
     real_t zcldl = zqlwc * t.rclc - t.zqlwc1 * pclc * rclc2;
     real_t ck = ck_l;
-    real_t zd = (2.0 * ck * zlcrit_l_r2) * t.zexp3 * t.zcldl * zcldl;
+    real_t zd = (RC(2.0) * ck * zlcrit_l_r2) * t.zexp3 * t.zcldl * zcldl;
     real_t zlnew = t.zcldl * t.zexpdl * pclc + t.clc * t.zexpdl * zcldl - t.clc * t.zcldl * t.zexpdl * zd;
     zprr = zqlwc - zlnew;
     zqlwc = zqlwc - zprr;
@@ -948,32 +988,32 @@ C2_HD void level_tl(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
     real_t zcldi = zqiwc * t.rclc - t.zqiwc1 * pclc * rclc2;
     real_t cki = ck_i;
     real_t zdi = cki * t.zexp1 *
-                 (t.zexp2 * (2.0 * t.zcldi * zcldi * zlcrit_i_r2 - 0.025 * ztp1) + 0.025 * ztp1);
+                 (t.zexp2 * (RC(2.0) * t.zcldi * zcldi * zlcrit_i_r2 - RC(0.025) * ztp1) + RC(0.025) * ztp1);
     real_t zinew = t.zcldi * t.zexpdi * pclc + t.clc * t.zexpdi * zcldi - t.clc * t.zcldi * t.zexpdi * zdi;
     zprs = zqiwc - zinew;
     zqiwc = zqiwc - zprs;
   }
   real_t zdr = zcons2 * (t.zdp * (zprr + zprs) + zdp * (t.zprr + t.zprs));
-  real_t zrfreeze = 0.0;
+  real_t zrfreeze = RC(0.0);
   if (t.frz1) zrfreeze = zcons2 * (zdp * t.zprr + t.zdp * zprr);
   zrfln = zrfln + t.zfwatr1 * zdr;
-  zsfln = zsfln + (1.0 - t.zfwatr1) * zdr;
+  zsfln = zsfln + (RC(1.0) - t.zfwatr1) * zdr;
 
   // J (cloudsc2tl.F90:844-936)
-  real_t zevapr = 0.0, zevaps = 0.0, pcovptot = 0.0;
+  real_t zevapr = RC(0.0), zevaps = RC(0.0), pcovptot = RC(0.0);
   if (t.llo2) {
     real_t zprtot = zrfln + zsfln;
     real_t zpreclr = (t.zprtot * zcovpclr + t.covpclr * zprtot) / t.covptot1 -
                      t.zprtot * t.covpclr * zcovptot / (t.covptot1 * t.covptot1);
     real_t omc2 = t.omc * t.omc;
     real_t zqe = dx.qs - ((x.qs - t.zqlim) * zcovpclr + t.covpclr * dx.qs - t.covpclr * zqlim) / omc2 -
-                 2.0 * (x.qs - t.zqlim) * t.covpclr * pclc / (omc2 * t.omc);
-    real_t zbeta = 0.5777 * (rg * c->rpecons / 5.09e-3) *
-                   pow(5.09e-3 * t.covpclr / (t.zpreclr1 * t.zsqp), 0.4223) *
-                   ((t.zsqp * zpreclr + 0.5 * t.zpreclr1 * dx.pap / sqrt(x.pap * x.paph_surf) -
-                     0.5 * t.zpreclr1 * t.zsqp * dx.paph_surf / x.paph_surf) / t.covpclr -
+                 RC(2.0) * (x.qs - t.zqlim) * t.covpclr * pclc / (omc2 * t.omc);
+    real_t zbeta = RC(0.5777) * (rg * c->rpecons / RC(5.09e-3)) *
+                   pow(RC(5.09e-3) * t.covpclr / (t.zpreclr1 * t.zsqp), RC(0.4223)) *
+                   ((t.zsqp * zpreclr + RC(0.5) * t.zpreclr1 * dx.pap / sqrt(x.pap * x.paph_surf) -
+                     RC(0.5) * t.zpreclr1 * t.zsqp * dx.paph_surf / x.paph_surf) / t.covpclr -
                     t.zpreclr1 * t.zsqp * zcovpclr / (t.covpclr * t.covpclr));
-    real_t den = 1.0 + t.zbeta * ptsphy * t.zcorqs;
+    real_t den = RC(1.0) + t.zbeta * ptsphy * t.zcorqs;
     real_t zb = ptsphy * ((x.qs - t.zqe) * zbeta + t.zbeta * dx.qs - t.zbeta * zqe) / den -
                 (ptsphy * ptsphy) * t.zbeta * (x.qs - t.zqe) * (t.zbeta * zcorqs + t.zcorqs * zbeta) / (den * den);
     real_t zdtgdp = -ptsphy * rg * (dx.paph_k1 - dx.paph_k) * rdp2;
@@ -989,8 +1029,8 @@ C2_HD void level_tl(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
   }
 
   // K (cloudsc2tl.F90:943-982)
-  real_t w5 = t.zfwat * t.zlvdcp + (1.0 - t.zfwat) * t.zlsdcp;
-  real_t w = zfwat * (t.zlvdcp - t.zlsdcp) + (t.zfwat * zlvdcp + (1.0 - t.zfwat) * zlsdcp);
+  real_t w5 = t.zfwat * t.zlvdcp + (RC(1.0) - t.zfwat) * t.zlsdcp;
+  real_t w = zfwat * (t.zlvdcp - t.zlsdcp) + (t.zfwat * zlvdcp + (RC(1.0) - t.zfwat) * zlsdcp);
   {
     real_t zdqdt = -(zcondl + zcondi) + (dx.lude + zevapr + zevaps) * t.zgdp + (x.lude + t.zevapr + t.zevaps) * zgdp;
     real_t zdtdt = zlvdcp * t.zcondl1 + zlsdcp * t.zcondi1 + t.zlvdcp * zcondl + t.zlsdcp * zcondi -
@@ -1012,10 +1052,10 @@ C2_HD void level_tl(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
       const real_t r4a = t.a_rtm4[it], r4a2 = r4a * r4a;
       real_t dfoeew = t.z3es * (rtt - t.z4es) * ztp1 * t.a_foeew[it] * r4a2;
       real_t dqsat = t.zqp * dfoeew + zqp * t.a_foeew[it];
-      if (t.a_clip[it]) dqsat = 0.0;
+      if (t.a_clip[it]) dqsat = RC(0.0);
       real_t dcor = (retv * dqsat) * (t.a_cor[it] * t.a_cor[it]);
       dqsat = t.a_qsatu[it] * dcor + dqsat * t.a_cor[it];
-      real_t dz2s = -2.0 * ztp1 * t.z5alcp * (r4a2 * r4a);
+      real_t dz2s = -RC(2.0) * ztp1 * t.z5alcp * (r4a2 * r4a);
       const real_t rden = t.a_rden[it];
       real_t dcond = (zqp1 - dqsat) * rden -
                      (t.a_q[it] - t.a_qsat[it]) *
@@ -1028,18 +1068,18 @@ C2_HD void level_tl(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
 
   // M (cloudsc2tl.F90:994-1091)
   {
-    real_t zdq = 0.0;
+    real_t zdq = RC(0.0);
     if (t.dq_pos) {
       zdq = zqold - zqp1;
-      if (lregcl) zdq = zdq * 0.7;
+      if (lregcl) zdq = zdq * RC(0.7);
     }
     real_t zdr2 = zcons2 * (t.zdp * zdq + t.zdq * zdp);
-    real_t zrfreeze2 = 0.0;
+    real_t zrfreeze2 = RC(0.0);
     if (t.frz2) zrfreeze2 = zfwat * t.zdr2 + t.zfwat * zdr2;
     zcondl = zcondl + (t.zfwatr2 * zdq) * zqtmst;
-    zcondi = zcondi + ((1.0 - t.zfwatr2) * zdq) * zqtmst;
+    zcondi = zcondi + ((RC(1.0) - t.zfwatr2) * zdq) * zqtmst;
     zrfln = zrfln + t.zfwatr2 * zdr2;
-    zsfln = zsfln + (1.0 - t.zfwatr2) * zdr2;
+    zsfln = zsfln + (RC(1.0) - t.zfwatr2) * zdr2;
     zrfreeze = zrfreeze + zrfreeze2;
 
     dout.tenq = -(zcondl + zcondi) + (dx.lude + zevapr + zevaps) * t.zgdp + (x.lude + t.zevapr + t.zevaps) * zgdp;
@@ -1088,15 +1128,15 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
   const int lregcl = c->lregcl, rvtmp2_zero = c->rvtmp2_zero;
   (void)r4ies; (void)r4les; (void)zcons3; (void)zmeltp2; (void)rvtmp2_zero;
   // adjoints of level-local quantities
-  real_t a_tp1 = 0.0, a_qp1 = 0.0, a_l = 0.0, a_i = 0.0, a_dp = 0.0;
-  real_t a_lvdcp = 0.0, a_lsdcp = 0.0, a_lfdcp = 0.0;
-  real_t a_qlwc = 0.0, a_qiwc = 0.0, a_condl = 0.0, a_condi = 0.0, a_evapr = 0.0, a_evaps = 0.0;
-  real_t a_rfreeze = 0.0, a_gdp = 0.0, a_fwat = 0.0, a_clc = ya.clc, a_lude_in = 0.0;
-  real_t a_pap = 0.0, a_qs = 0.0, a_mfu = 0.0, a_mfd = 0.0, a_lu_k1 = 0.0, a_paph_k = 0.0, a_paph_k1 = 0.0;
-  real_t a_paph_surf = 0.0;
-  real_t a_covptot = acy.covptot, a_covpclr = 0.0, a_qlim = 0.0, a_corqs = 0.0, a_dqsdtemp = 0.0;
+  real_t a_tp1 = RC(0.0), a_qp1 = RC(0.0), a_l = RC(0.0), a_i = RC(0.0), a_dp = RC(0.0);
+  real_t a_lvdcp = RC(0.0), a_lsdcp = RC(0.0), a_lfdcp = RC(0.0);
+  real_t a_qlwc = RC(0.0), a_qiwc = RC(0.0), a_condl = RC(0.0), a_condi = RC(0.0), a_evapr = RC(0.0), a_evaps = RC(0.0);
+  real_t a_rfreeze = RC(0.0), a_gdp = RC(0.0), a_fwat = RC(0.0), a_clc = ya.clc, a_lude_in = RC(0.0);
+  real_t a_pap = RC(0.0), a_qs = RC(0.0), a_mfu = RC(0.0), a_mfd = RC(0.0), a_lu_k1 = RC(0.0), a_paph_k = RC(0.0), a_paph_k1 = RC(0.0);
+  real_t a_paph_surf = RC(0.0);
+  real_t a_covptot = acy.covptot, a_covpclr = RC(0.0), a_qlim = RC(0.0), a_corqs = RC(0.0), a_dqsdtemp = RC(0.0);
 
-  const real_t w5 = t.zfwat * t.zlvdcp + (1.0 - t.zfwat) * t.zlsdcp;
+  const real_t w5 = t.zfwat * t.zlvdcp + (RC(1.0) - t.zfwat) * t.zlsdcp;
 
   // fluxes leaving the level (cloudsc2ad.F90:941-957)
   real_t a_sfln = acy.sfl + ya.fplsn;
@@ -1116,7 +1156,7 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
     a_lsdcp += zdtdt * (t.zcondi2 - t.zevaps * t.zgdp);
     a_lude_in -= zdtdt * t.zgdp * w5;
     a_lvdcp -= zdtdt * x.lude * t.zgdp * t.zfwat;
-    a_lsdcp -= zdtdt * x.lude * t.zgdp * (1.0 - t.zfwat);
+    a_lsdcp -= zdtdt * x.lude * t.zgdp * (RC(1.0) - t.zfwat);
     a_fwat -= zdtdt * x.lude * t.zgdp * (t.zlvdcp - t.zlsdcp);
     a_lsdcp += zdtdt * t.zrfreeze3 * t.zgdp;
     a_lvdcp -= zdtdt * t.zrfreeze3 * t.zgdp;
@@ -1130,12 +1170,12 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
   }
 
   // M^T: extra condensation to precipitation (cloudsc2ad.F90:1017-1063)
-  real_t a_qold = 0.0;
+  real_t a_qold = RC(0.0);
   {
     real_t zrfreeze2 = a_rfreeze;
     real_t zsn = a_sfln, zrn = a_rfln;
-    real_t a_dq = a_condi * (1.0 - t.zfwatr2) * zqtmst + a_condl * t.zfwatr2 * zqtmst;
-    real_t zdr2 = (1.0 - t.zfwatr2) * zsn + t.zfwatr2 * zrn;
+    real_t a_dq = a_condi * (RC(1.0) - t.zfwatr2) * zqtmst + a_condl * t.zfwatr2 * zqtmst;
+    real_t zdr2 = (RC(1.0) - t.zfwatr2) * zsn + t.zfwatr2 * zrn;
     if (t.frz2) {
       a_fwat += t.zdr2 * zrfreeze2;
       zdr2 += t.zfwat * zrfreeze2;
@@ -1143,7 +1183,7 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
     a_dq += zcons2 * t.zdp * zdr2;
     a_dp += zcons2 * t.zdq * zdr2;
     if (t.dq_pos) {
-      if (lregcl) a_dq *= 0.7;
+      if (lregcl) a_dq *= RC(0.7);
       a_qold += a_dq;
       a_qp1 -= a_dq;
     }
@@ -1151,7 +1191,7 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
 
   // L^T: saturation adjustment (cuadjtqsad.F90:542-641)
   {
-    real_t a_zqp = 0.0;
+    real_t a_zqp = RC(0.0);
 #pragma unroll
     for (int it = 1; it >= 0; --it) {
       const real_t rden = t.a_rden[it];
@@ -1163,11 +1203,11 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
       zqsat -= zcond1 * dqmq * t.a_cor[it] * t.a_z2s[it];
       real_t zcor = -zcond1 * dqmq * t.a_qsat[it] * t.a_z2s[it];
       real_t z2s = -zcond1 * dqmq * t.a_qsat[it] * t.a_cor[it];
-      real_t ztarg = -2.0 * z2s * t.z5alcp * (r4a2 * r4a);
+      real_t ztarg = -RC(2.0) * z2s * t.z5alcp * (r4a2 * r4a);
       zcor += zqsat * t.a_qsatu[it];
       zqsat = zqsat * t.a_cor[it];
       zqsat += zcor * retv * (t.a_cor[it] * t.a_cor[it]);
-      if (t.a_clip[it]) zqsat = 0.0;
+      if (t.a_clip[it]) zqsat = RC(0.0);
       real_t zfoeew = zqsat * t.zqp;
       a_zqp += zqsat * t.a_foeew[it];
       ztarg += zfoeew * t.z3es * (rtt - t.z4es) * t.a_foeew[it] * r4a2;
@@ -1190,7 +1230,7 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
     a_lsdcp += zdtdt * (t.zcondi1 - t.zevaps * t.zgdp);
     a_lude_in -= zdtdt * t.zgdp * w5;
     a_lvdcp -= zdtdt * x.lude * t.zgdp * t.zfwat;
-    a_lsdcp -= zdtdt * x.lude * t.zgdp * (1.0 - t.zfwat);
+    a_lsdcp -= zdtdt * x.lude * t.zgdp * (RC(1.0) - t.zfwat);
     a_fwat -= zdtdt * x.lude * t.zgdp * (t.zlvdcp - t.zlsdcp);
     a_lsdcp += zdtdt * t.zrfreeze1 * t.zgdp;
     a_lvdcp -= zdtdt * t.zrfreeze1 * t.zgdp;
@@ -1204,9 +1244,9 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
   }
 
   // J^T: evaporation of precipitation (cloudsc2ad.F90:1152-1261)
-  real_t a_prtot = 0.0;
+  real_t a_prtot = RC(0.0);
   if (t.llo2) {
-    real_t zdpr = 0.0, zpreclr = 0.0, zb = 0.0, zbeta = 0.0, zqe = 0.0, a_dtgdp = 0.0;
+    real_t zdpr = RC(0.0), zpreclr = RC(0.0), zb = RC(0.0), zbeta = RC(0.0), zqe = RC(0.0), a_dtgdp = RC(0.0);
     // ice proportion
     a_evaps -= a_sfln;
     a_sfln += t.zdpr * a_evaps / t.zprtot;
@@ -1219,9 +1259,9 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
     a_prtot -= t.zdpr * t.rfln2 * a_evapr / (t.zprtot * t.zprtot);
     // clear-sky flux
     a_covptot += ya.covptot;
-    if (t.reset) { a_clc += a_covptot; a_covptot = 0.0; }
+    if (t.reset) { a_clc += a_covptot; a_covptot = RC(0.0); }
     zdpr -= zpreclr;
-    if (t.dpr_clip) { zpreclr += zdpr; zdpr = 0.0; }
+    if (t.dpr_clip) { zpreclr += zdpr; zdpr = RC(0.0); }
     zb += t.covpclr * zdpr / t.zdtgdp;
     a_covpclr += t.zb * zdpr / t.zdtgdp;
     a_dtgdp -= t.covpclr * t.zb * zdpr / (t.zdtgdp * t.zdtgdp);
@@ -1231,17 +1271,17 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
       a_paph_k += g;
     }
     // implicit solution
-    real_t den = 1.0 + t.zbeta * ptsphy * t.zcorqs;
+    real_t den = RC(1.0) + t.zbeta * ptsphy * t.zcorqs;
     zbeta += ptsphy * (x.qs - t.zqe) * zb / den;
     a_qs += ptsphy * t.zbeta * zb / den;
     zqe -= ptsphy * t.zbeta * zb / den;
     a_corqs -= (ptsphy * ptsphy) * t.zbeta * (x.qs - t.zqe) * t.zbeta * zb / (den * den);
     zbeta -= (ptsphy * ptsphy) * t.zbeta * (x.qs - t.zqe) * t.zcorqs * zb / (den * den);
     // zbeta
-    real_t zxx = 0.5777 * (rg * c->rpecons / 5.09e-3) * pow(5.09e-3 * t.covpclr / (t.zpreclr1 * t.zsqp), 0.4223);
+    real_t zxx = RC(0.5777) * (rg * c->rpecons / RC(5.09e-3)) * pow(RC(5.09e-3) * t.covpclr / (t.zpreclr1 * t.zsqp), RC(0.4223));
     zpreclr += zxx * t.zsqp * zbeta / t.covpclr;
-    a_pap += (zxx * 0.5 * t.zpreclr1 * zbeta / sqrt(x.pap * x.paph_surf)) / t.covpclr;
-    a_paph_surf -= (zxx * 0.5 * t.zpreclr1 * t.zsqp * zbeta / x.paph_surf) / t.covpclr;
+    a_pap += (zxx * RC(0.5) * t.zpreclr1 * zbeta / sqrt(x.pap * x.paph_surf)) / t.covpclr;
+    a_paph_surf -= (zxx * RC(0.5) * t.zpreclr1 * t.zsqp * zbeta / x.paph_surf) / t.covpclr;
     a_covpclr -= zxx * t.zpreclr1 * t.zsqp * zbeta / (t.covpclr * t.covpclr);
     // zqe
     real_t omc2 = t.omc * t.omc;
@@ -1249,21 +1289,21 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
     a_covpclr -= (x.qs - t.zqlim) * zqe / omc2;
     a_qs -= t.covpclr * zqe / omc2;
     a_qlim += t.covpclr * zqe / omc2;
-    a_clc -= 2.0 * (x.qs - t.zqlim) * t.covpclr * zqe / (omc2 * t.omc);
+    a_clc -= RC(2.0) * (x.qs - t.zqlim) * t.covpclr * zqe / (omc2 * t.omc);
     // zpreclr
     a_covpclr += t.zprtot * zpreclr / t.covptot1;
     a_prtot += t.covpclr * zpreclr / t.covptot1;
     a_covptot -= t.zprtot * t.covpclr * zpreclr / (t.covptot1 * t.covptot1);
-    a_evapr = 0.0;
-    a_evaps = 0.0;
+    a_evapr = RC(0.0);
+    a_evaps = RC(0.0);
   }
 
   // I^T: new precipitation and autoconversion (cloudsc2ad.F90:1265-1356)
   {
     a_rfln += a_prtot;
     a_sfln += a_prtot;
-    real_t zdr = (1.0 - t.zfwatr1) * a_sfln + t.zfwatr1 * a_rfln;
-    real_t zprr = 0.0, zprs = 0.0;
+    real_t zdr = (RC(1.0) - t.zfwatr1) * a_sfln + t.zfwatr1 * a_rfln;
+    real_t zprr = RC(0.0), zprs = RC(0.0);
     if (t.frz1) {
       a_dp += a_rfreeze * zcons2 * t.zprr;
       zprr += a_rfreeze * zcons2 * t.zdp;
@@ -1280,8 +1320,8 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
       real_t zcldi = zinew * t.clc * t.zexpdi;
       real_t zdi = -zinew * t.clc * t.zcldi * t.zexpdi;
       real_t cki = ck_i;
-      a_tp1 += cki * t.zexp1 * (1.0 - t.zexp2) * 0.025 * zdi;
-      zcldi += (cki * t.zexp1 * t.zexp2 * 2.0 * t.zcldi * zlcrit_i_r2) * zdi;
+      a_tp1 += cki * t.zexp1 * (RC(1.0) - t.zexp2) * RC(0.025) * zdi;
+      zcldi += (cki * t.zexp1 * t.zexp2 * RC(2.0) * t.zcldi * zlcrit_i_r2) * zdi;
       a_qiwc += zcldi * t.rclc;
       a_clc -= t.zqiwc1 * zcldi * (t.rclc * t.rclc);
       // liquid
@@ -1292,14 +1332,14 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
       real_t zcldl = zlnew * t.clc * t.zexpdl;
       real_t zdl = -zlnew * t.clc * t.zcldl * t.zexpdl;
       real_t ck = ck_l;
-      zcldl += (2.0 * ck * zlcrit_l_r2) * t.zexp3 * t.zcldl * zdl;
+      zcldl += (RC(2.0) * ck * zlcrit_l_r2) * t.zexp3 * t.zcldl * zdl;
       a_qlwc += zcldl * t.rclc;
       a_clc -= t.zqlwc1 * zcldl * (t.rclc * t.rclc);
     }
   }
 
   // H^T: melting of incoming snow (cloudsc2ad.F90:1362-1400)
-  real_t a_sfl = 0.0, a_rfl = 0.0;
+  real_t a_sfl = RC(0.0), a_rfl = RC(0.0);
   if (t.melt) {
     real_t zsnmlt = -a_tp1 * t.rcons;
     real_t zcons = (a_tp1 * t.zsnmlt) * (t.rcons * t.rcons);
@@ -1307,7 +1347,7 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
     zsnmlt -= a_sfln;
     a_rfl += a_rfln;
     zsnmlt += a_rfln;
-    real_t zz2s = 0.0;
+    real_t zz2s = RC(0.0);
     if (t.melt_all) a_sfl += zsnmlt; else zz2s += zsnmlt;
     if (t.warm2) {
       a_tp1 += t.zcons * zz2s;
@@ -1321,26 +1361,26 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
   }
 
   // G^T: overlap (cloudsc2ad.F90:1407-1418)
-  if (t.covpclr1 < 0.0) a_covpclr = 0.0;
+  if (t.covpclr1 < RC(0.0)) a_covpclr = RC(0.0);
   a_covptot += a_covpclr;
   a_clc -= a_covpclr;
-  if (t.newmax) { a_clc += a_covptot; a_covptot = 0.0; }
+  if (t.newmax) { a_clc += a_covptot; a_covptot = RC(0.0); }
 
   // F^T (cloudsc2ad.F90:1425-1441)
-  real_t a_qc = 0.0;
+  real_t a_qc = RC(0.0);
   a_qiwc += a_condi * zqtmst;  a_i -= a_condi * zqtmst;
   a_qlwc += a_condl * zqtmst;  a_l -= a_condl * zqtmst;
-  a_qc += a_qiwc * (1.0 - t.zfwat);
+  a_qc += a_qiwc * (RC(1.0) - t.zfwat);
   a_fwat -= a_qiwc * t.zqc3;
   a_qc += a_qlwc * t.zfwat;
   a_fwat += a_qlwc * t.zqc3;
 
   // E^T: subsidence (cloudsc2ad.F90:1447-1495)
-  real_t a_foeew = 0.0;
+  real_t a_foeew = RC(0.0);
   {
-    real_t zdqc = -a_qc, zdqsdz = 0.0, zrho = 0.0;
+    real_t zdqc = -a_qc, zdqsdz = RC(0.0), zrho = RC(0.0);
     if (t.llo3) {
-      if (lregcl) zdqc *= 0.1;
+      if (lregcl) zdqc *= RC(0.1);
       zdqsdz += zdqc * ptsphy * (x.mfu + x.mfd) * t.zfac4;
       a_mfu += zdqc * ptsphy * t.zdqsdz * t.zfac4;
       a_mfd += zdqc * ptsphy * t.zdqsdz * t.zfac4;
@@ -1356,7 +1396,7 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
     a_dqsdtemp -= dtdzmo * t.dtdzmo * t.zldcp * t.zfac3;
     a_fwat += zldcp * (t.zlvdcp - t.zlsdcp);
     a_lvdcp += zldcp * t.zfwat;
-    a_lsdcp += zldcp * (1.0 - t.zfwat);
+    a_lsdcp += zldcp * (RC(1.0) - t.zfwat);
     zrho -= zrodqsdp * x.qs * t.zfac2;
     a_qs -= zrodqsdp * t.zrho * t.zfac2;
     a_pap += zrodqsdp * t.zrho * x.qs * (t.zfac2 * t.zfac2);
@@ -1367,12 +1407,12 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
 
   // D^T: convective component (cloudsc2ad.F90:1501-1526)
   {
-    real_t zlude = 0.0;
+    real_t zlude = RC(0.0);
     if (t.llo1) {
       zlude += a_qc;
-      zlude += ((1.0 - t.zclc) * t.rlu) * t.zexpl * a_clc;
-      a_lu_k1 -= ((1.0 - t.zclc) * t.zlude * (t.rlu * t.rlu)) * t.zexpl * a_clc;
-      a_clc = a_clc * (1.0 - (1.0 - t.zexpl));
+      zlude += ((RC(1.0) - t.zclc) * t.rlu) * t.zexpl * a_clc;
+      a_lu_k1 -= ((RC(1.0) - t.zclc) * t.zlude * (t.rlu * t.rlu)) * t.zexpl * a_clc;
+      a_clc = a_clc * (RC(1.0) - (RC(1.0) - t.zexpl));
     }
     a_lude_in += ptsphy * t.zgdp * zlude;
     a_gdp += ptsphy * x.lude * zlude;
@@ -1382,20 +1422,20 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
   }
 
   // C^T: cloud cover (cloudsc2ad.F90:1532-1582)
-  real_t a_qsat = 0.0, a_qcrit = 0.0;
+  real_t a_qsat = RC(0.0), a_qcrit = RC(0.0);
   {
-    real_t zqt = 0.0;
+    real_t zqt = RC(0.0);
     if (t.regime == 0) {
       // nothing propagates
     } else if (t.regime == 1) {
-      a_qsat += (1.0 - k.zscalm) * a_qc;
-      a_qcrit -= (1.0 - k.zscalm) * a_qc;
+      a_qsat += (RC(1.0) - k.zscalm) * a_qc;
+      a_qcrit -= (RC(1.0) - k.zscalm) * a_qc;
     } else {
       real_t zqpd = k.zscalm * a_qc * (t.zclc * t.zclc);
-      real_t zqcd = (1.0 - k.zscalm) * a_qc * (t.zclc * t.zclc);
-      a_clc += (k.zscalm * t.zqpd + (1.0 - k.zscalm) * t.zqcd) * 2.0 * t.zclc * a_qc;
+      real_t zqcd = (RC(1.0) - k.zscalm) * a_qc * (t.zclc * t.zclc);
+      a_clc += (k.zscalm * t.zqpd + (RC(1.0) - k.zscalm) * t.zqcd) * RC(2.0) * t.zclc * a_qc;
       if (lregcl) a_clc = regcl_factor(t.zqpd, t.zqcd, k.zscalm) * a_clc;
-      const real_t h = 0.5 * t.rzsqrt, rden2 = t.rden * t.rden;
+      const real_t h = RC(0.5) * t.rzsqrt, rden2 = t.rden * t.rden;
       zqpd -= h * a_clc * t.rden;
       zqcd += h * (t.zqpd * a_clc) * rden2;
       zqt -= h * (t.zqpd * k.zscalm * a_clc) * rden2;
@@ -1415,7 +1455,7 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
     a_qsat += a_qcrit * t.zcrh2;
     a_qs += a_qsat * t.zsupsat;
     real_t zsupsat = a_qsat * x.qs;
-    if (t.below_rtice) a_tp1 -= zsupsat * 3.e-03;
+    if (t.below_rtice) a_tp1 -= zsupsat * RC(3.e-03);
     if (t.qlim_is_qs) a_qs += a_qlim; else a_qp1 += a_qlim;
 
     a_dqsdtemp += zcons3 * a_corqs;
@@ -1425,18 +1465,18 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
     real_t zesdp = retv * zcor * (t.zcor * t.zcor);
     real_t zfacw = t.zfwat * zfac;
     a_fwat += t.zfacw * zfac;
-    real_t zfaci = (1.0 - t.zfwat) * zfac;
+    real_t zfaci = (RC(1.0) - t.zfwat) * zfac;
     a_fwat -= t.zfaci * zfac;
-    a_tp1 -= 2.0 * r5ies * zfaci * (t.ri * t.ri * t.ri);
-    a_tp1 -= 2.0 * r5les * zfacw * (t.rl * t.rl * t.rl);
-    if (t.esdp_clip) zesdp = 0.0;
+    a_tp1 -= RC(2.0) * r5ies * zfaci * (t.ri * t.ri * t.ri);
+    a_tp1 -= RC(2.0) * r5les * zfacw * (t.rl * t.rl * t.rl);
+    if (t.esdp_clip) zesdp = RC(0.0);
     a_foeew += zesdp * t.zqp;
     a_pap -= zesdp * t.zfoeew * (t.zqp * t.zqp);
     real_t z3es, z4es, r4;
     if (t.cold) { z3es = r3ies; z4es = r4ies; r4 = t.ri; }
     else        { z3es = r3les; z4es = r4les; r4 = t.rl; }
     a_tp1 += z3es * (rtt - z4es) * a_foeew * t.zfoeew * (r4 * r4);
-    if (t.cold) a_tp1 += 0.545 * 0.17 * a_fwat * t.zcosh2r;
+    if (t.cold) a_tp1 += RC(0.545) * RC(0.17) * a_fwat * t.zcosh2r;
   }
 
   // thermodynamic constants and first guess (cloudsc2ad.F90:1701-1738)

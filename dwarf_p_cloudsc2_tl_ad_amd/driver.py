@@ -16,12 +16,13 @@ from . import binding as B
 from .state import PLANE_A, PLANE_Q, PLANE_QI, PLANE_QL, PLANE_QV, PLANE_T, Cloudsc2State, nblocks_of
 
 _dp = C.POINTER(C.c_double)
+_rp = C.POINTER(B.c_real)
 
 
 def _ptr(a: np.ndarray):
-    if a.dtype != np.float64 or not a.flags["C_CONTIGUOUS"]:
-        raise ValueError("state arrays must be C-contiguous float64")
-    return a.ctypes.data_as(_dp)
+    if a.dtype != B.REAL or not a.flags["C_CONTIGUOUS"]:
+        raise ValueError(f"state arrays must be C-contiguous {np.dtype(B.REAL).name}")
+    return a.ctypes.data_as(_rp)
 
 
 def _host_args(prm: B.Params, nproma, nlev, ngptot, ptsphy, arrays):
@@ -78,7 +79,7 @@ def run_state(prm: B.Params, st: Cloudsc2State, which: str = "nl"):
 # ---------------------------------------------------------------------------------------------------------------------
 def _fld(t, offset_elems: int, stride: int) -> B.Field:
     f = B.Field()
-    f.ptr = t.data_ptr() + 8 * offset_elems
+    f.ptr = t.data_ptr() + B.REAL_BYTES * offset_elems
     f.block_stride = stride
     return f
 
@@ -93,7 +94,7 @@ class FlatFields:
         names = B.IN_NAMES if kind == "in" else B.OUT_NAMES
         half = {"paph"} if kind == "in" else {"fplsl", "fplsn", "fhpsl", "fhpsn"}
         mk = torch.zeros if zero else torch.empty
-        self.t = {n: mk((nb, nlev + (1 if n in half else 0), nproma), dtype=torch.float64, device=device) for n in names}
+        self.t = {n: mk((nb, nlev + (1 if n in half else 0), nproma), dtype=B.torch_real(), device=device) for n in names}
         self.nlev, self.nproma = nlev, nproma
 
     def block(self):
@@ -141,7 +142,7 @@ class DeviceState:
         self.nb = nblocks_of(ngptot, nproma)
         self._keep = []
         period = klon if period is None else period
-        z = lambda *shape: torch.zeros(shape, dtype=torch.float64, device=self.device)  # noqa: E731
+        z = lambda *shape: torch.zeros(shape, dtype=B.torch_real(), device=self.device)  # noqa: E731
         for n in self.FULL:
             setattr(self, n, z(self.nb, nlev, nproma))
         for n in self.HALF:
@@ -155,9 +156,9 @@ class DeviceState:
                  ("TENDENCY_CML_QL", self.B_CML, PLANE_QL * S, 8 * S), ("TENDENCY_CML_QI", self.B_CML, PLANE_QI * S, 8 * S),
                  ("PCLV_QL", self.PCLV, 0, 5 * S), ("PCLV_QI", self.PCLV, S, 5 * S)]
         for name, dst, off, stride in jobs:
-            src = torch.from_numpy(np.ascontiguousarray(tab[name], dtype=np.float64)).to(self.device)
+            src = torch.from_numpy(np.ascontiguousarray(tab[name], dtype=B.REAL)).to(self.device)
             self._keep.append(src)
-            B.check(B.lib.cloudsc2_expand_launch(C.cast(src.data_ptr(), C.POINTER(C.c_double)), klon, period, start,
+            B.check(B.lib.cloudsc2_expand_launch(C.cast(src.data_ptr(), _rp), klon, period, start,
                                                  src.shape[0], 1, nproma, ngptot, _fld(dst, off, stride), self._stream(stream)))
         return self
 
@@ -177,12 +178,12 @@ class DeviceState:
                   "TENDENCY_LOC_CLD": "TENDENCY_LOC%CLD"}
         rows, keep = [], []
         for name, fld, off, stride, ndim in plan:
-            tabdev = torch.from_numpy(np.ascontiguousarray(ref[name], dtype=np.float64)).to(self.device)
+            tabdev = torch.from_numpy(np.ascontiguousarray(ref[name], dtype=B.REAL)).to(self.device)
             keep.append(tabdev)
             klon = tabdev.shape[-1]
             nlevx = tabdev.shape[-2]
             stats = torch.empty(5, dtype=torch.float64, device=self.device)
-            B.check(B.lib.cloudsc2_validate_launch(dp(tabdev), klon, klon if period is None else period, start, nlevx, ndim,
+            B.check(B.lib.cloudsc2_validate_launch(C.cast(tabdev.data_ptr(), _rp), klon, klon if period is None else period, start, nlevx, ndim,
                                                    self.nproma, self.ngptot, _fld(fld, off, stride), dp(ws), dp(stats),
                                                    self._stream(stream)))
             rows.append((labels.get(name, name), 2 if ndim == 1 else 3, stats))
@@ -272,7 +273,7 @@ class DeviceState:
         return ff
 
     def new_scratch(self):
-        return self.torch.empty((self.nb, self.nlev, self.nproma), dtype=self.torch.float64, device=self.device)
+        return self.torch.empty((self.nb, self.nlev, self.nproma), dtype=B.torch_real(), device=self.device)
 
     def download(self, st: Cloudsc2State) -> Cloudsc2State:
         for n in ("B_LOC", "PA", "PCOVPTOT", "PFPLSL", "PFPLSN", "PFHPSL", "PFHPSN"):

@@ -134,7 +134,7 @@ def _tile(field2d: np.ndarray, nproma: int, ngptot: int, col0: int = 0) -> np.nd
 
 @dataclasses.dataclass
 class Cloudsc2State:
-    """Host-side GLOBAL_STATE (numpy, fp64).  Field names are the reference's."""
+    """Host-side GLOBAL_STATE (numpy; fp64, or fp32 under CLOUDSC2_PRECISION=single).  Field names are the reference's."""
 
     nproma: int
     nlev: int
@@ -187,7 +187,8 @@ class Cloudsc2State:
         }
 
 
-def state_from_table(tab: dict, nproma: int, ngptot: int, col0: int = 0, poison_outputs: float | None = None) -> Cloudsc2State:
+def state_from_table(tab: dict, nproma: int, ngptot: int, col0: int = 0, poison_outputs: float | None = None,
+                     real=None) -> Cloudsc2State:
     """LOAD of cloudsc2_array_state_mod.F90:153-203 with the table standing in for input.h5: tile the inputs
     (LOAD_AND_EXPAND, :167-182) and zero-initialise the outputs (FIELD_INIT, :186-190)."""
     nlev = tab["PT"].shape[0]
@@ -204,29 +205,43 @@ def state_from_table(tab: dict, nproma: int, ngptot: int, col0: int = 0, poison_
     fill = 0.0 if poison_outputs is None else poison_outputs
     full = lambda: np.full((nb, nlev, nproma), fill)  # noqa: E731
     half = lambda: np.full((nb, nlev + 1, nproma), fill)  # noqa: E731
+    if real is None:
+        from .binding import REAL as real  # the precision of the loaded library (CLOUDSC2_PRECISION)
+    if np.dtype(real) != np.float64:  # JPRB = fp32: the fp64 file data are rounded on load, as under the reference's -DSINGLE
+        t0, full0, half0 = t, full, half
+        t = lambda name: t0(name).astype(real)  # noqa: E731
+        full = lambda: full0().astype(real)  # noqa: E731
+        half = lambda: half0().astype(real)  # noqa: E731
+        b_cml, pclv = b_cml.astype(real), pclv.astype(real)
     return Cloudsc2State(
         nproma=nproma, nlev=nlev, ngptot=ngptot, ptsphy=float(tab["PTSPHY"]),
-        PT=t("PT"), PQ=t("PQ"), B_CML=b_cml, B_LOC=np.full((nb, 8, nlev, nproma), fill),
+        PT=t("PT"), PQ=t("PQ"), B_CML=b_cml, B_LOC=np.full((nb, 8, nlev, nproma), fill, dtype=real),
         PAP=t("PAP"), PAPH=t("PAPH"), PLU=t("PLU"), PLUDE=t("PLUDE"), PMFU=t("PMFU"), PMFD=t("PMFD"),
         PA=t("PA") if poison_outputs is None else full(), PCLV=pclv, PSUPSAT=t("PSUPSAT"),
         PCOVPTOT=full(), PFPLSL=half(), PFPLSN=half(), PFHPSL=half(), PFHPSN=half(),
     )
 
 
-def bytes_per_column(nlev: int, kernel: str = "nl") -> int:
+def bytes_per_column(nlev: int, kernel: str = "nl", real_bytes: int | None = None) -> int:
     """Algorithmic HBM bytes per column: every input plane read once, every output plane written once."""
+    if real_bytes is None:
+        from .binding import REAL_BYTES as real_bytes
+    return (real_bytes * _reals_per_column(nlev, kernel))
+
+
+def _reals_per_column(nlev: int, kernel: str) -> int:
     full, half = nlev, nlev + 1
     nl_in = half + 14 * full                 # PAPH + 14 full-level planes (PQS comes from the fused SATUR)
     nl_out = 6 * full + 4 * half             # PTEN{T,Q,L,I}, PCLC, PCOVPTOT + 4 flux planes
     if kernel == "nl":
-        return 8 * (nl_in + nl_out)
+        return nl_in + nl_out
     if kernel == "nl_driver":                # + the driver's CLD(:,:,NCLV)=0 plane
-        return 8 * (nl_in + nl_out + full)
+        return nl_in + nl_out + full
     if kernel == "tl":
-        return 8 * (nl_in + full + (half + 15 * full) + 2 * nl_out)
+        return nl_in + full + (half + 15 * full) + 2 * nl_out
     if kernel == "ad":
         x = half + 15 * full
-        return 8 * ((nl_in + full) + nl_out + x + nl_out + x + nl_out)
+        return (nl_in + full) + nl_out + x + nl_out + x + nl_out
     raise ValueError(kernel)
 
 

@@ -4,8 +4,10 @@
  * This is the drop-in boundary for the hot path of ecmwf-ifs/dwarf-p-cloudsc2-tl-ad.  The reference has
  * no FFI layer; its de-facto boundary is the three driver procedures and the F77-style kernels they call
  * (SURVEY.md 8b).  Every entry point below cites the reference interface it replaces (paths relative to
- * the reference checkout).  All arrays are fp64 (JPRB, src/common/module/parkind1.F90:43) in the
- * reference's NPROMA-blocked layout, column index fastest:
+ * the reference checkout).  All arrays are `cloudsc2_real` = JPRB (src/common/module/parkind1.F90:40-44): fp64 in
+ * libcloudsc2_hip.so, fp32 in libcloudsc2_hip_sp.so (this header compiled with -DCLOUDSC2_SINGLE, the reference's
+ * -DSINGLE; same entry points, cloudsc2_real_bytes() tells the two apart).  Constants, time step, test statistics and
+ * norms are `double` in both.  Layout: the reference's NPROMA-blocked one, column index fastest:
  *
  *     field(NPROMA, NLEV or NLEV+1, NBLOCKS)         f[jl + NPROMA*(jk + NLEVx*ibl)]
  *     B_CML / B_LOC (NPROMA, NLEV, 8, NBLOCKS)       planes T=0, A=1, Q=2, CLD(QL,QI,QR,QS,QV)=3..7
@@ -21,6 +23,12 @@
 
 #ifdef __cplusplus
 extern "C" {
+#endif
+
+#ifdef CLOUDSC2_SINGLE
+typedef float cloudsc2_real;
+#else
+typedef double cloudsc2_real;
 #endif
 
 #define CLOUDSC2_MAX_NLEV 200 /* the reference's own limit, src/cloudsc2_nl/dwarf_cloudsc.F90:87 */
@@ -57,6 +65,8 @@ void cloudsc2_params_default(cloudsc2_params* p);
 const char* cloudsc2_last_error(void);
 /* 1 if a HIP device is usable by this process, else 0. */
 int cloudsc2_device_available(void);
+/* sizeof(cloudsc2_real) of THIS build of the library: 8, or 4 for the -DCLOUDSC2_SINGLE build. */
+int cloudsc2_real_bytes(void);
 
 /* Arithmetic of the kernels (process-wide; initial value from the environment variable CLOUDSC2_MATH=fast|precise).
  *   0 fast (default): quotients on shared / batch-inverted v_rcp_f64 reciprocals refined by two Newton steps, a
@@ -68,12 +78,12 @@ int cloudsc2_get_math_mode(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Kernel level: DEVICE pointers, asynchronous on `stream` (a hipStream_t, NULL = default stream).
- * One field = base pointer + stride between NPROMA blocks (in doubles); level stride is NPROMA,
+ * One field = base pointer + stride between NPROMA blocks (in elements); level stride is NPROMA,
  * column stride 1.  A (NPROMA,NLEV,NBLOCKS) array has block_stride NPROMA*NLEV; plane p of B_CML has
  * ptr = b_cml + p*NPROMA*NLEV and block_stride 8*NPROMA*NLEV.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct cloudsc2_field {
-  double* ptr;
+  cloudsc2_real* ptr;
   long long block_stride;
 } cloudsc2_field;
 
@@ -116,12 +126,12 @@ int cloudsc2_tl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
 /* CLOUDSC2AD (src/cloudsc2_ad/cloudsc2ad.F90:10-24): trajectory in -> trajectory out; adj_out holds the
  * output adjoints on entry and is zeroed on return (:917-919,955-966,1173,1572,1678-1691); adj_in is
  * accumulated (+=, :1723-1738) except PSUPSAT which is assigned PTSPHY*zqp1 exactly as the reference does
- * (:1733).  `scratch` must hold (ngptot rounded up to NPROMA blocks) * nlev doubles (precipitation-cover
+ * (:1733).  `scratch` must hold (ngptot rounded up to NPROMA blocks) * nlev elements (precipitation-cover
  * carry checkpoints). */
 int cloudsc2_ad_launch(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
                        const cloudsc2_inputs* traj_in, const cloudsc2_outputs* traj_out,
                        const cloudsc2_inputs* adj_in, const cloudsc2_outputs* adj_out,
-                       double* scratch, void* stream);
+                       cloudsc2_real* scratch, void* stream);
 
 /* Taylor-test statistics for one lambda (ERROR_NORM, cloudsc_driver_tl_mod.F90:21-31, calls :233-244):
  * for each NPROMA block and each of the 10 output fields, sums over the block's active columns and all
@@ -152,30 +162,30 @@ int cloudsc2_adjoint_norms_launch(int nproma, int nlev, int ngptot, const clouds
  * the sum over the slabs' launches).
  * ------------------------------------------------------------------------------------------------ */
 int cloudsc2_nl_run(const cloudsc2_params* prm, int nproma, int nlev, int ngptot, double ptsphy,
-                    const double* pt, const double* pq, const double* b_cml, double* b_loc,
-                    const double* pap, const double* paph, const double* plu, const double* plude,
-                    const double* pmfu, const double* pmfd, double* pa, const double* pclv,
-                    const double* psupsat, double* pcovptot, double* pfplsl, double* pfplsn,
-                    double* pfhpsl, double* pfhpsn, double* kernel_ms);
+                    const cloudsc2_real* pt, const cloudsc2_real* pq, const cloudsc2_real* b_cml, cloudsc2_real* b_loc,
+                    const cloudsc2_real* pap, const cloudsc2_real* paph, const cloudsc2_real* plu, const cloudsc2_real* plude,
+                    const cloudsc2_real* pmfu, const cloudsc2_real* pmfd, cloudsc2_real* pa, const cloudsc2_real* pclv,
+                    const cloudsc2_real* psupsat, cloudsc2_real* pcovptot, cloudsc2_real* pfplsl, cloudsc2_real* pfplsn,
+                    cloudsc2_real* pfhpsl, cloudsc2_real* pfhpsn, double* kernel_ms);
 
 /* CLOUDSC_DRIVER_TL (src/cloudsc2_tl/cloudsc_driver_tl_mod.F90:33-314): NL, 1 % increments, TL, ten
  * perturbed NL runs, ERROR_NORM per block, max over blocks.  znormg[10] receives the raw ratios
  * (the values printed at :275).  Returns CLOUDSC2_ETLWRONG where the reference STOPs (:247-249). */
 int cloudsc2_tl_taylor_run(const cloudsc2_params* prm, int nproma, int nlev, int ngptot, double ptsphy,
-                           const double* pt, const double* pq, const double* b_cml, double* b_loc,
-                           const double* pap, const double* paph, const double* plu, const double* plude,
-                           const double* pmfu, const double* pmfd, double* pa, const double* pclv,
-                           const double* psupsat, double* pcovptot, double* pfplsl, double* pfplsn,
-                           double* pfhpsl, double* pfhpsn, double znormg[10], double* kernel_ms);
+                           const cloudsc2_real* pt, const cloudsc2_real* pq, const cloudsc2_real* b_cml, cloudsc2_real* b_loc,
+                           const cloudsc2_real* pap, const cloudsc2_real* paph, const cloudsc2_real* plu, const cloudsc2_real* plude,
+                           const cloudsc2_real* pmfu, const cloudsc2_real* pmfd, cloudsc2_real* pa, const cloudsc2_real* pclv,
+                           const cloudsc2_real* psupsat, cloudsc2_real* pcovptot, cloudsc2_real* pfplsl, cloudsc2_real* pfplsn,
+                           cloudsc2_real* pfhpsl, cloudsc2_real* pfhpsn, double znormg[10], double* kernel_ms);
 
 /* CLOUDSC_DRIVER_AD (src/cloudsc2_ad/cloudsc_driver_ad_mod.F90:22-297): TL, norm1, zero, AD, norm2,
  * norm3; *znormg = max over columns of norm3 (the value printed at :287). */
 int cloudsc2_ad_symmetry_run(const cloudsc2_params* prm, int nproma, int nlev, int ngptot, double ptsphy,
-                             const double* pt, const double* pq, const double* b_cml, double* b_loc,
-                             const double* pap, const double* paph, const double* plu, const double* plude,
-                             const double* pmfu, const double* pmfd, double* pa, const double* pclv,
-                             const double* psupsat, double* pcovptot, double* pfplsl, double* pfplsn,
-                             double* pfhpsl, double* pfhpsn, double* znormg, double* kernel_ms);
+                             const cloudsc2_real* pt, const cloudsc2_real* pq, const cloudsc2_real* b_cml, cloudsc2_real* b_loc,
+                             const cloudsc2_real* pap, const cloudsc2_real* paph, const cloudsc2_real* plu, const cloudsc2_real* plude,
+                             const cloudsc2_real* pmfu, const cloudsc2_real* pmfd, cloudsc2_real* pa, const cloudsc2_real* pclv,
+                             const cloudsc2_real* psupsat, cloudsc2_real* pcovptot, cloudsc2_real* pfplsl, cloudsc2_real* pfplsn,
+                             cloudsc2_real* pfhpsl, cloudsc2_real* pfhpsn, double* znormg, double* kernel_ms);
 
 void cloudsc2_release_workspace(void);
 
@@ -202,10 +212,10 @@ int cloudsc2_adjoint_verdict(double znormg);
  *   max |FIELD-REF|, sum |FIELD-REF|, sum |REF| (active columns) }.  `workspace` (device) needs
  *   cloudsc2_validate_workspace_doubles() doubles.  Sums are folded in a fixed order (deterministic).
  * ------------------------------------------------------------------------------------------------ */
-int cloudsc2_expand_launch(const double* table, int klon, int period, long long start, int nlevx, int ndim,
+int cloudsc2_expand_launch(const cloudsc2_real* table, int klon, int period, long long start, int nlevx, int ndim,
                            int nproma, long long ngptot, cloudsc2_field field, void* stream);
 int cloudsc2_validate_workspace_doubles(void);
-int cloudsc2_validate_launch(const double* table, int klon, int period, long long start, int nlevx, int ndim,
+int cloudsc2_validate_launch(const cloudsc2_real* table, int klon, int period, long long start, int nlevx, int ndim,
                              int nproma, long long ngptot, cloudsc2_field field, double* workspace,
                              double* stats, void* stream);
 /* GET_OFFSETS (expand_mod.F90:30-46): which table columns rank `irank` of `numproc` tiles from.

@@ -2,6 +2,7 @@
 
 * ``RefLib``    : oracle/_ref/libcloudsc2_ref.so, the UNMODIFIED reference Fortran compiled by oracle/Makefile
                   (exists only where /root/reference was present at build time, or where the prebuilt .so travelled);
+                  ``RefLib(single=True)`` is the same sources built with the reference's -DSINGLE (fp32 arrays);
 * ``OracleLib`` : oracle/libcloudsc2_oracle.so, the plain-C restatement (oracle/cloudsc2_oracle.c).
 
 Both take one NPROMA block at a time as Fortran ``(KLON, KLEV)`` arrays = numpy C-ordered ``(KLEV, KLON)``.
@@ -17,6 +18,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF_PATH = os.path.join(HERE, "_ref", "libcloudsc2_ref.so")
+REF_PATH_SP = os.path.join(HERE, "_ref", "libcloudsc2_ref_sp.so")
 ORACLE_PATH = os.path.join(HERE, "libcloudsc2_oracle.so")
 
 _dp = C.POINTER(C.c_double)
@@ -26,9 +28,9 @@ OUT10 = ("tent", "tenq", "tenl", "teni", "clc", "fplsl", "fplsn", "fhpsl", "fhps
 HALF = {"paph", "fplsl", "fplsn", "fhpsl", "fhpsn"}
 
 
-def _p(a: np.ndarray):
-    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"], "need C-contiguous float64"
-    return a.ctypes.data_as(_dp)
+def _p(a: np.ndarray, dtype=np.float64):
+    assert a.dtype == dtype and a.flags["C_CONTIGUOUS"], f"need C-contiguous {np.dtype(dtype).name}"
+    return a.ctypes.data_as(C.c_void_p)
 
 
 def big_stack(fn, *args, stack_mb: int = 1024, **kw):
@@ -62,12 +64,12 @@ def kernel_arg_order(inp: dict, out: dict):
             out["covptot"]]
 
 
-def new_outputs(klev: int, klon: int, fill: float = 0.0) -> dict:
-    return {n: np.full((klev + (1 if n in HALF else 0), klon), fill) for n in OUT10}
+def new_outputs(klev: int, klon: int, fill: float = 0.0, dtype=np.float64) -> dict:
+    return {n: np.full((klev + (1 if n in HALF else 0), klon), fill, dtype=dtype) for n in OUT10}
 
 
-def new_inputs(klev: int, klon: int, fill: float = 0.0) -> dict:
-    return {n: np.full((klev + (1 if n in HALF else 0), klon), fill) for n in IN16}
+def new_inputs(klev: int, klon: int, fill: float = 0.0, dtype=np.float64) -> dict:
+    return {n: np.full((klev + (1 if n in HALF else 0), klon), fill, dtype=dtype) for n in IN16}
 
 
 class _KernelLib:
@@ -75,81 +77,87 @@ class _KernelLib:
 
     prefix = ""
 
-    def __init__(self, path: str):
+    def __init__(self, path: str, dtype=np.float64):
         if not os.path.exists(path):
             raise FileNotFoundError(path)
         self.lib = C.CDLL(path)
         self.path = path
+        self.dtype = dtype  # element type of the field arrays (constants and PTSPHY are always C doubles)
+        vp = C.c_void_p
         f = getattr(self.lib, self.prefix + "set_params")
         f.argtypes = [_dp, C.c_int, C.c_int, C.c_int, C.c_int, _dp]
         f.restype = None
         f = getattr(self.lib, self.prefix + "satur")
-        f.argtypes = [C.c_int] * 4 + [_dp] * 3
+        f.argtypes = [C.c_int] * 4 + [vp] * 3
         f.restype = None
         f = getattr(self.lib, self.prefix + "cloudsc2")
-        f.argtypes = [C.c_int] * 5 + [C.c_double] + [_dp] * 26
+        f.argtypes = [C.c_int] * 5 + [C.c_double] + [vp] * 26
         f.restype = None
         for n in ("cloudsc2tl", "cloudsc2ad"):
             f = getattr(self.lib, self.prefix + n)
-            f.argtypes = [C.c_int] * 5 + [C.c_double] + [_dp] * 52
+            f.argtypes = [C.c_int] * 5 + [C.c_double] + [vp] * 52
             f.restype = None
+
+    def _a(self, a: np.ndarray):
+        return _p(a, self.dtype)
 
     def set_params(self, doubles30: np.ndarray, ceta: np.ndarray, lphylin=True, levapls2=False, lregcl=False):
         r = np.ascontiguousarray(doubles30, dtype=np.float64)
         ce = np.ascontiguousarray(ceta, dtype=np.float64)
         assert r.size == 30
-        getattr(self.lib, self.prefix + "set_params")(_p(r), int(lphylin), int(levapls2), int(lregcl), int(ce.size), _p(ce))
+        getattr(self.lib, self.prefix + "set_params")(r.ctypes.data_as(_dp), int(lphylin), int(levapls2), int(lregcl),
+                                                      int(ce.size), ce.ctypes.data_as(_dp))
         self.nlev = int(ce.size)
 
     def satur(self, pap: np.ndarray, t: np.ndarray, kfdia: int | None = None) -> np.ndarray:
         klev, klon = pap.shape
         q = np.zeros_like(pap)
-        getattr(self.lib, self.prefix + "satur")(1, kfdia or klon, klon, klev, _p(pap), _p(t), _p(q))
+        getattr(self.lib, self.prefix + "satur")(1, kfdia or klon, klon, klev, self._a(pap), self._a(t), self._a(q))
         return q
 
     def cloudsc2(self, ptsphy: float, inp: dict, out: dict | None = None, ldrain1d=False, kfdia: int | None = None) -> dict:
         klev, klon = inp["pap"].shape
-        out = out if out is not None else new_outputs(klev, klon)
+        out = out if out is not None else new_outputs(klev, klon, dtype=self.dtype)
         args = kernel_arg_order(inp, out)
         # the kernels keep (KLON,KLEV) work arrays on the stack (cloudsc2.F90:176-190): large KLON needs a large stack
         big_stack(getattr(self.lib, self.prefix + "cloudsc2"), 1, kfdia or klon, klon, klev, int(ldrain1d), float(ptsphy),
-                  *[_p(a) for a in args])
+                  *[self._a(a) for a in args])
         return out
 
     def cloudsc2tl(self, ptsphy: float, inp5: dict, dinp: dict, out5: dict | None = None, dout: dict | None = None,
                    ldrain1d=False, kfdia: int | None = None):
         klev, klon = inp5["pap"].shape
-        out5 = out5 if out5 is not None else new_outputs(klev, klon)
-        dout = dout if dout is not None else new_outputs(klev, klon)
+        out5 = out5 if out5 is not None else new_outputs(klev, klon, dtype=self.dtype)
+        dout = dout if dout is not None else new_outputs(klev, klon, dtype=self.dtype)
         args = kernel_arg_order(inp5, out5) + kernel_arg_order(dinp, dout)
         big_stack(getattr(self.lib, self.prefix + "cloudsc2tl"), 1, kfdia or klon, klon, klev, int(ldrain1d), float(ptsphy),
-                  *[_p(a) for a in args])
+                  *[self._a(a) for a in args])
         return out5, dout
 
     def cloudsc2ad(self, ptsphy: float, inp5: dict, ainp: dict, aout: dict, out5: dict | None = None, ldrain1d=False,
                    kfdia: int | None = None):
         """ainp (input adjoints, accumulated) and aout (output adjoints, zeroed on return) are modified in place."""
         klev, klon = inp5["pap"].shape
-        out5 = out5 if out5 is not None else new_outputs(klev, klon)
+        out5 = out5 if out5 is not None else new_outputs(klev, klon, dtype=self.dtype)
         args = kernel_arg_order(inp5, out5) + kernel_arg_order(ainp, aout)
         fn = getattr(self.lib, self.prefix + "cloudsc2ad")
-        big_stack(fn, 1, kfdia or klon, klon, klev, int(ldrain1d), float(ptsphy), *[_p(a) for a in args])
+        big_stack(fn, 1, kfdia or klon, klon, klev, int(ldrain1d), float(ptsphy), *[self._a(a) for a in args])
         return out5
 
 
 class RefLib(_KernelLib):
     prefix = "ref_"
 
-    def __init__(self, path: str = REF_PATH):
-        super().__init__(path)
-        self.lib.ref_driver.argtypes = [C.c_int] * 5 + [C.c_double] + [_dp] * 18
+    def __init__(self, path: str | None = None, single: bool = False):
+        super().__init__(path or (REF_PATH_SP if single else REF_PATH), np.float32 if single else np.float64)
+        self.lib.ref_driver.argtypes = [C.c_int] * 5 + [C.c_double] + [C.c_void_p] * 18
         self.lib.ref_driver.restype = None
 
     def driver(self, which: int, numomp: int, nproma: int, nlev: int, ngptot: int, ptsphy: float, arrays18):
         """CLOUDSC_DRIVER (0) / _TL (1) / _AD (2) on GLOBAL_STATE arrays in the order of cloudsc_driver_mod.F90:22-30.
         The TL and AD drivers print their verdict on stdout."""
         os.environ.setdefault("OMP_STACKSIZE", "1G")
-        big_stack(self.lib.ref_driver, which, numomp, nproma, nlev, ngptot, float(ptsphy), *[_p(a) for a in arrays18])
+        big_stack(self.lib.ref_driver, which, numomp, nproma, nlev, ngptot, float(ptsphy), *[self._a(a) for a in arrays18])
 
 
 class OracleLib(_KernelLib):
@@ -159,8 +167,8 @@ class OracleLib(_KernelLib):
         super().__init__(path)
 
 
-def have_ref() -> bool:
-    return os.path.exists(REF_PATH)
+def have_ref(single: bool = False) -> bool:
+    return os.path.exists(REF_PATH_SP if single else REF_PATH)
 
 
 def have_oracle() -> bool:

@@ -116,7 +116,7 @@ int hostcheck_tl(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev
 }
 
 int hostcheck_ad(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot, const cloudsc2_inputs* in,
-                 const cloudsc2_outputs* out, const cloudsc2_inputs* ain, const cloudsc2_outputs* aout, double* scratch) {
+                 const cloudsc2_outputs* out, const cloudsc2_inputs* ain, const cloudsc2_outputs* aout, cloudsc2_real* scratch) {
   AdArgs a;
   a.nl.g = hc_geom(nproma, nlev, ngptot);
   a.nl.c = hc_consts(*prm, ptsphy);

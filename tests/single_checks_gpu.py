@@ -1,0 +1,155 @@
+"""GPU half of tests/single_checks.py (fp32 kernels of libcloudsc2_hip_sp.so through the C ABI)."""
+from __future__ import annotations
+
+import numpy as np
+
+from tests.single_checks import F32, adjoint_identity, compare_blocks, qsat_blocks, refs
+from tests.util import B, c2, make_params, refcall, relerr
+
+
+def _np(ff):
+    return {n: t.cpu().numpy() for n, t in ff.t.items()}
+
+
+def gpu_checks():
+    import torch
+
+    assert B.device_available(), "no HIP device"
+    ok = True
+    for flags, precise in ((dict(), False), (dict(levapls2=True, lregcl=True), False), (dict(), True)):
+        B.set_math_mode(precise)
+        tab = c2.random_table(137, 300, seed=5)
+        prm = make_params(tab, **flags)
+        r32, r64 = refs(prm)
+        nproma, ngptot = 64, 300  # 5 blocks, ragged tail of 44
+        st = c2.state_from_table(tab, nproma, ngptot)
+        nb, nlev = st.nblocks, st.nlev
+        print(f"gpu fp32: flags={flags} precise={precise}")
+
+        ds = c2.DeviceState(st)
+        assert ds.PT.dtype == torch.float32
+        ds.satur(prm)
+        torch.cuda.synchronize()
+        qsat = ds.QSAT.cpu().numpy()
+        qref = qsat_blocks(r32, st)
+        for ibl in range(nb):
+            icend = min(nproma, ngptot - ibl * nproma)
+            e = relerr(qref[ibl][:, :icend].astype(np.float64), qsat[ibl][:, :icend].astype(np.float64))
+            assert e < 2e-6, ("satur", e)
+        # use the reference's PQS so that every later difference is the kernels' own
+        ds.QSAT.copy_(torch.from_numpy(qref))
+        inc = ds.increments()
+        tlo = c2.FlatFields("out", nb, nlev, nproma, ds.device)
+        ds.tl(prm, inc, tlo)
+        torch.cuda.synchronize()
+        got = ds.download(st.copy())
+        tl, incn = _np(tlo), _np(inc)
+
+        # the NL kernel (fused SATUR off: same PQS) gives the trajectory the TL kernel stored
+        ds2 = c2.DeviceState(st)
+        ds2.QSAT.copy_(torch.from_numpy(qref))
+        ds2.nl(prm, fused_satur=False)
+        torch.cuda.synchronize()
+        got_nl = ds2.download(st.copy())
+        for n in ("B_LOC", "PA", "PCOVPTOT", "PFPLSL", "PFPLSN", "PFHPSL", "PFHPSN"):
+            a, b = getattr(got, n), getattr(got_nl, n)
+            if n == "B_LOC":  # plane QV is zeroed by the NL launch only
+                a, b = a[:, :7], b[:, :7]
+            assert np.array_equal(a, b), ("NL and TL trajectories differ", n)
+
+        # AD applied to y = the fp32 reference's TL outputs
+        y = c2.FlatFields("out", nb, nlev, nproma, ds.device)
+        for ibl in range(nb):
+            icend = min(nproma, ngptot - ibl * nproma)
+            inp = refcall.block_inputs(st, ibl, qref[ibl])
+            dinp = {n: np.ascontiguousarray(incn[n][ibl]) for n in incn}
+            for d in (inp, dinp):
+                for a in d.values():
+                    a[:, icend:] = 1.0
+            _, d32 = r32.cloudsc2tl(st.ptsphy, inp, dinp, kfdia=icend)
+            for n in d32:
+                blk = np.zeros_like(d32[n])
+                blk[:, :icend] = d32[n][:, :icend]
+                y.t[n][ibl].copy_(torch.from_numpy(blk))
+        x = c2.FlatFields("in", nb, nlev, nproma, ds.device)
+        ds.ad(prm, x, y, ds.new_scratch())
+        torch.cuda.synchronize()
+        for n, t in y.t.items():
+            assert float(t.abs().max()) == 0.0, ("output adjoint not consumed", n)
+        ok &= compare_blocks(st, got, tl, _np(x), incn, qref, r32, r64)
+
+        # adjoint identity with our own TL outputs as y
+        y2 = c2.FlatFields("out", nb, nlev, nproma, ds.device)
+        for n in y2.t:
+            y2.t[n].copy_(tlo.t[n])
+        x2 = c2.FlatFields("in", nb, nlev, nproma, ds.device)
+        ds.ad(prm, x2, y2, ds.new_scratch())
+        torch.cuda.synchronize()
+        ok &= adjoint_identity(st, tl, incn, _np(x2), "gpu") < 2e-4
+    B.set_math_mode(False)
+
+    # driver level (host arrays, slab-pipelined transfers) = kernel level, bit for bit; untouched planes keep their values
+    tab = c2.synthetic_table()
+    prm = make_params(tab)
+    st = c2.state_from_table(tab, 128, 1000, poison_outputs=-5.0)
+    ref = st.copy()
+    ms = c2.run_state(prm, st, "nl")
+    ds = c2.DeviceState(ref)
+    ds.nl(prm)
+    torch.cuda.synchronize()
+    ds.download(ref)
+    for n in ("PA", "PCOVPTOT", "PFPLSL", "PFPLSN", "PFHPSL", "PFHPSN"):
+        assert np.array_equal(getattr(st, n), getattr(ref, n)), n
+    assert np.array_equal(st.B_LOC[:, [0, 2, 3, 4, 7]], ref.B_LOC[:, [0, 2, 3, 4, 7]])
+    assert np.all(st.B_LOC[:, [1, 5, 6]] == F32(-5.0))
+    print(f"driver-level NL == kernel-level NL (kernel {ms:.3f} ms for 1000 columns)")
+
+    # the adjoint test driver in fp32: norm3 is in units of the fp32 epsilon (cloudsc_driver_ad_mod.F90:262-264)
+    st = c2.state_from_table(tab, 100, 100)
+    zn, passed, _ = c2.run_state(prm, st, "ad")
+    print(f"CLOUDSC_DRIVER_AD fp32: max norm3 = {zn:.3f} eps -> {'TEST OK' if passed else 'TEST FAILED'}")
+    ok &= bool(passed)
+    try:
+        znormg, tpass, itest, _ = c2.run_state(prm, c2.state_from_table(tab, 100, 100), "tl")
+        print("CLOUDSC_DRIVER_TL fp32 (informative: the V shape needs fp64 head-room):", np.array2string(znormg, precision=3),
+              "PASSED" if tpass else f"FAILED itest={itest}")
+    except c2.Cloudsc2Error as e:
+        print("CLOUDSC_DRIVER_TL fp32 (informative):", e)
+
+    # device-side tiling and validation in fp32
+    tab = c2.random_table(137, 100, seed=3)
+    prm = make_params(tab)
+    a = c2.DeviceState.from_table(tab, 96, 1000)
+    b = c2.DeviceState(c2.state_from_table(tab, 96, 1000))
+    for n in a.FULL + a.HALF + ("B_CML", "PCLV"):
+        assert torch.equal(getattr(a, n), getattr(b, n)), n
+    a.nl(prm)
+    torch.cuda.synchronize()
+    from dwarf_p_cloudsc2_tl_ad_amd import fileio
+
+    host = a.download(c2.state_from_table(tab, 96, 1000))
+    reft = fileio.reference_table_from_state(host, 100)
+    rows, text = a.validate(reft)
+    for name, _, s in rows:
+        assert s[2] == 0.0 and s[3] == 0.0, (name, s)
+    print(text.splitlines()[0])
+    print(text.splitlines()[1])
+
+    # throughput (informative)
+    n = 160000
+    tab = c2.synthetic_table()
+    prm = make_params(tab)
+    ds = c2.DeviceState.from_table(tab, 128, n)
+    for _ in range(3):
+        ds.nl(prm)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(10):
+        ds.nl(prm)
+    ev[1].record()
+    torch.cuda.synchronize()
+    t = ev[0].elapsed_time(ev[1]) / 10
+    gbs = c2.bytes_per_column(137) * n / t / 1e6
+    print(f"fp32 NL {n} columns: {t:.3f} ms, {n / t * 1e3:.3e} columns/s, {gbs:.0f} GB/s algorithmic")
+    return ok

@@ -1,0 +1,51 @@
+"""The fp32 build (the reference's -DSINGLE): libcloudsc2_hip_sp.so against the reference Fortran
+compiled with -DSINGLE (oracle/_ref/libcloudsc2_ref_sp.so).  A process works in ONE precision (like one binary of the
+reference), so the checks run in a child process with CLOUDSC2_PRECISION=single; see tests/single_checks.py for what
+is asserted and the tolerances."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import pytest
+
+from tests.util import ROOT, refcall
+
+SP_LIB = os.path.join(ROOT, "dwarf_p_cloudsc2_tl_ad_amd", "csrc", "libcloudsc2_hip_sp.so")
+
+
+def _child(what: str, timeout: int):
+    env = dict(os.environ, CLOUDSC2_PRECISION="single", CLOUDSC2_MATH="fast")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "single_checks.py"), what], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=timeout)
+    print(p.stdout[-6000:])
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert "SINGLE CHECKS PASSED" in p.stdout
+    return p.stdout
+
+
+def test_single_library_exports_the_same_abi():
+    from dwarf_p_cloudsc2_tl_ad_amd import binding as B
+
+    assert os.path.exists(SP_LIB), "libcloudsc2_hip_sp.so not built (make -C dwarf_p_cloudsc2_tl_ad_amd/csrc libcloudsc2_hip_sp.so)"
+    lib = C.CDLL(SP_LIB)
+    for name in B.EXPORTED:
+        assert hasattr(lib, name), name
+    lib.cloudsc2_real_bytes.restype = C.c_int
+    assert lib.cloudsc2_real_bytes() == 4
+    assert B.lib.cloudsc2_real_bytes() == 8
+
+
+@pytest.mark.skipif(not refcall.have_ref(single=True), reason="oracle/_ref/libcloudsc2_ref_sp.so not built")
+def test_single_column_code_on_host():
+    out = _child("host", 900)
+    assert out.count("FAIL") == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not refcall.have_ref(single=True), reason="oracle/_ref/libcloudsc2_ref_sp.so not built")
+def test_single_kernels_on_gpu():
+    out = _child("gpu", 900)
+    assert "driver-level NL == kernel-level NL" in out and "TEST OK" in out

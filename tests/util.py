@@ -17,7 +17,7 @@ from dwarf_p_cloudsc2_tl_ad_amd import binding as B  # noqa: E402
 from oracle import refcall  # noqa: E402
 
 HOSTCHECK_DIR = os.path.join(ROOT, "tests", "hostcheck")
-HOSTCHECK_LIB = os.path.join(HOSTCHECK_DIR, "libhostcheck.so")
+HOSTCHECK_LIB = os.path.join(HOSTCHECK_DIR, "libhostcheck_sp.so" if B.SINGLE else "libhostcheck.so")
 
 
 def build_hostcheck() -> str:
@@ -25,7 +25,7 @@ def build_hostcheck() -> str:
     deps = [src] + [os.path.join(ROOT, "dwarf_p_cloudsc2_tl_ad_amd", "csrc", f) for f in ("cloudsc2_level.hpp", "cloudsc2_column.hpp")]
     if (not os.path.exists(HOSTCHECK_LIB)) or any(os.path.getmtime(d) > os.path.getmtime(HOSTCHECK_LIB) for d in deps):
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--cuda-host-only", "-O2", "-ffp-contract=off", "-fPIC", "-shared",
-                               "-std=c++17", "-o", HOSTCHECK_LIB, src])
+                               "-std=c++17"] + (["-DCLOUDSC2_SINGLE"] if B.SINGLE else []) + ["-o", HOSTCHECK_LIB, src])
     return HOSTCHECK_LIB
 
 
@@ -50,9 +50,9 @@ def hostcheck():
 
 
 def hfld(a: np.ndarray, offset: int = 0, stride: int | None = None) -> B.Field:
-    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    assert a.dtype == B.REAL and a.flags["C_CONTIGUOUS"]
     f = B.Field()
-    f.ptr = a.ctypes.data + 8 * offset
+    f.ptr = a.ctypes.data + B.REAL_BYTES * offset
     f.block_stride = stride if stride is not None else int(np.prod(a.shape[1:]))
     return f
 
@@ -79,7 +79,7 @@ def host_traj_blocks(st: c2.Cloudsc2State, qsat: np.ndarray | None = None):
 
 def flat_fields(kind: str, nb: int, nlev: int, nproma: int, fill: float = 0.0) -> dict:
     names = B.IN_NAMES if kind == "in" else B.OUT_NAMES
-    return {n: np.full((nb, nlev + (1 if n in refcall.HALF else 0), nproma), fill) for n in names}
+    return {n: np.full((nb, nlev + (1 if n in refcall.HALF else 0), nproma), fill, dtype=B.REAL) for n in names}
 
 
 def flat_block(kind: str, arrays: dict):
@@ -94,7 +94,7 @@ def increments_of(st: c2.Cloudsc2State, qsat: np.ndarray, zero_supsat: bool = Fa
     src = {"paph": st.PAPH, "pap": st.PAP, "q": st.PQ, "qsat": qsat, "t": st.PT, "l": st.PCLV[:, 0], "i": st.PCLV[:, 1],
            "lude": st.PLUDE, "lu": st.PLU, "mfu": st.PMFU, "mfd": st.PMFD, "gtent": st.B_CML[:, 0], "gtenq": st.B_CML[:, 2],
            "gtenl": st.B_CML[:, 3], "gteni": st.B_CML[:, 4], "supsat": st.PSUPSAT}
-    out = {n: np.ascontiguousarray(a * 0.01) for n, a in src.items()}
+    out = {n: np.ascontiguousarray(a * B.REAL(0.01)) for n, a in src.items()}
     if zero_supsat:
         out["supsat"][...] = 0.0
     return out
