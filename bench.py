@@ -53,13 +53,14 @@ def cpu_baseline(tab, prm, nproma, ngptot, budget_s=20.0):
 
     cores = effective_cores()
     st = c2.state_from_table(tab, nproma, ngptot)
-    if refcall.have_ref():
-        lib, kind = refcall.RefLib(), "reference"
+    single = c2.binding.SINGLE
+    if refcall.have_ref(single=single):
+        lib, kind = refcall.RefLib(single=single), "reference"
         lib.set_params(prm.doubles30(), prm.ceta_array())
         os.environ.setdefault("OMP_SCHEDULE", "static")
         arrays = st.driver_arrays()
         run = lambda: lib.driver(0, cores, nproma, st.nlev, ngptot, st.ptsphy, arrays)  # noqa: E731
-    elif refcall.have_oracle():
+    elif refcall.have_oracle() and not single:
         lib, kind = refcall.OracleLib(), "port"
         lib.set_params(prm.doubles30(), prm.ceta_array())
         import ctypes as C
@@ -113,6 +114,8 @@ def main():
     ap.add_argument("--nproma", type=int, default=128)
     ap.add_argument("--kernel", choices=["nl", "tl", "ad"], default="nl")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=["double", "single"], default=os.environ.get("CLOUDSC2_PRECISION", "double"),
+                    help="single = the fp32 library (the reference's -DSINGLE build); the headline metric is double")
     ap.add_argument("--levapls2", action="store_true", help="switch the evaporation branch on (off in every shipped config)")
     ap.add_argument("--placement-regions", default="0,30,60,90,120,150,180,210",
                     help="GiB offsets in HBM at which candidate placements of the state are timed before the measurement "
@@ -121,8 +124,12 @@ def main():
 
     import torch
 
+    os.environ["CLOUDSC2_PRECISION"] = args.precision  # read by the package at import: one precision per process
     import dwarf_p_cloudsc2_tl_ad_amd as c2
     from dwarf_p_cloudsc2_tl_ad_amd import dist as c2dist
+
+    single = c2.binding.SINGLE
+    fp = "fp32" if single else "fp64"
 
     rank, local, world = c2dist.init_process_group()
     if not torch.cuda.is_available() or not c2.device_available():
@@ -221,6 +228,7 @@ def main():
     traffic = None
     pmc_files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("pmc_traffic.json")) \
         if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+    pmc_files = [f for f in pmc_files if ("_sp_" in f) == single]  # counters are per precision
     if pmc_files:
         try:
             pmcs = [json.load(open(os.path.join(ROOT, "profiles", f))) for f in pmc_files]
@@ -234,11 +242,11 @@ def main():
                 "algorithmic_bytes": bpc * args.ngptot, "kernel_ms_avg": k_avg, "kernel_ms_min": float(kms.min())}
 
     out = {
-        "metric": f"CLOUDSC2 {args.kernel.upper()} columns/sec (fp64, NLEV=137)", "value": value, "unit": "columns/s",
+        "metric": f"CLOUDSC2 {args.kernel.upper()} columns/sec ({fp}, NLEV=137)", "value": value, "unit": "columns/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"CLOUDSC2 {args.kernel.upper()} fp64, NGPTOT={args.ngptot} columns per GPU, NLEV=137, "
-                               f"NPROMA={args.nproma} (BASELINE.json configs[1])",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if single else "f64", "data": "synthetic",
+        "config": {"workload": f"CLOUDSC2 {args.kernel.upper()} {fp}, NGPTOT={args.ngptot} columns per GPU, NLEV=137, "
+                               f"NPROMA={args.nproma} (BASELINE.json configs[1]{", the -DSINGLE variant" if single else ""})",
                    "ngptot_per_gpu": args.ngptot, "nlev": nlev, "nproma": args.nproma,
                    "parallelism": f"columns sharded over {world} GPU(s), no data-path collective",
                    "device": device_info(torch, dev),

@@ -365,7 +365,7 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
   if (PERT) paph_k = pert(paph_k, lam);
   // offsets used inside the level loop, in the variant's offset type
   const LaneOffT<OT> ol = lane_off_as<OT>(o);
-  const OT ozl = (OT)(ozero * (OFF32 ? 8 : 1)), oscl = (OT)(osc * (OFF32 ? 8 : 1));
+  const OT ozl = (OT)(ozero * (OFF32 ? (long long)sizeof(real_t) : 1)), oscl = (OT)(osc * (OFF32 ? (long long)sizeof(real_t) : 1));
 
   // one level: `cur` holds the raw inputs of level jk (requested one level ago), `nxt` receives those of level jk+1
   auto step = [&](int jk, RawLevel& cur, RawLevel& nxt) {
@@ -581,7 +581,7 @@ C2_HD void ad_reverse_column(long long gcol, AdArgsP a) {
   const long long osc64 = (gcol / nproma) * ((long long)nproma * nlev) + (gcol % nproma);
   // offsets used inside the level loop, in the variant's offset type
   const LaneOffT<OT> ol = lane_off_as<OT>(o), oa = lane_off_as<OT>(oa64);
-  const OT osc = (OT)(osc64 * (OFF32 ? 8 : 1));
+  const OT osc = (OT)(osc64 * (OFF32 ? (long long)sizeof(real_t) : 1));
 
   real_t ztrpaus = tropopause<false>(c, tab, in, o, &a->nl.g, RC(0.0));
   RhCrit rh;

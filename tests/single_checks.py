@@ -153,6 +153,42 @@ def host_checks():
         assert hc.hostcheck_ad(C.byref(prm), st.ptsphy, nproma, nlev, ngptot, C.byref(i3), C.byref(o3), C.byref(ai), C.byref(ao),
                                scratch.ctypes.data) == 0
         ok &= adjoint_identity(st, tl, inc, x2, "host") < 2e-4
+
+        # the 32-bit byte-offset variants of the sweeps (what the GPU launches for buffers < 4 GiB) give the same bits:
+        # NL with the driver's zero plane, TL, AD with its checkpoint plane
+        hc.hostcheck_set_off32(1)
+        try:
+            S = nproma * nlev
+            nl64, nl32 = st.copy(), st.copy()
+            for off32, tgt in ((0, nl64), (1, nl32)):
+                hc.hostcheck_set_off32(off32)
+                tgt.B_LOC[...] = F32(-5.0)
+                ii, oo = host_traj_blocks(tgt, qsat)
+                zero = B.Field()
+                zero.ptr = tgt.B_LOC.ctypes.data + 4 * 7 * S
+                zero.block_stride = 8 * S
+                assert hc.hostcheck_nl(C.byref(prm), st.ptsphy, nproma, nlev, ngptot, C.byref(ii), C.byref(oo), zero, 0.0) == 0
+                assert np.all(tgt.B_LOC[:, 7] == 0.0) and np.all(tgt.B_LOC[:, [1, 5, 6]] == F32(-5.0))
+            for n in ("B_LOC", "PA", "PCOVPTOT", "PFPLSL", "PFPLSN", "PFHPSL", "PFHPSN"):
+                assert np.array_equal(getattr(nl64, n), getattr(nl32, n)), ("off32 NL", n)
+            tl32 = flat_fields("out", nb, nlev, nproma)
+            got4 = st.copy()
+            i4, o4 = host_traj_blocks(got4, qsat)
+            di, do_ = flat_block("in", inc), flat_block("out", tl32)
+            assert hc.hostcheck_tl(C.byref(prm), st.ptsphy, nproma, nlev, ngptot, C.byref(i4), C.byref(o4), C.byref(di), C.byref(do_)) == 0
+            y3 = {n: a.copy() for n, a in tl32.items()}
+            x3 = flat_fields("in", nb, nlev, nproma)
+            guard = np.full((nb + 1, nlev, nproma), F32(7.0))  # one spare block behind the checkpoint plane
+            ai, ao = flat_block("in", x3), flat_block("out", y3)
+            assert hc.hostcheck_ad(C.byref(prm), st.ptsphy, nproma, nlev, ngptot, C.byref(i4), C.byref(o4), C.byref(ai), C.byref(ao),
+                                   guard.ctypes.data) == 0
+            assert np.all(guard[nb] == F32(7.0)), "checkpoint stores ran past the scratch plane"
+            for n in tl:
+                assert np.array_equal(tl[n], tl32[n]), ("off32 TL", n)
+            for n in x2:
+                assert np.array_equal(x2[n], x3[n]), ("off32 AD", n)
+        finally:
+            hc.hostcheck_set_off32(0)
         hc.hostcheck_set_precise(0)
     return ok
 
