@@ -130,6 +130,7 @@ def main():
 
     single = c2.binding.SINGLE
     fp = "fp32" if single else "fp64"
+    variant = ", the -DSINGLE variant" if single else ""
 
     rank, local, world = c2dist.init_process_group()
     if not torch.cuda.is_available() or not c2.device_available():
@@ -246,7 +247,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if single else "f64", "data": "synthetic",
         "config": {"workload": f"CLOUDSC2 {args.kernel.upper()} {fp}, NGPTOT={args.ngptot} columns per GPU, NLEV=137, "
-                               f"NPROMA={args.nproma} (BASELINE.json configs[1]{", the -DSINGLE variant" if single else ""})",
+                               f"NPROMA={args.nproma} (BASELINE.json configs[1]{variant})",
                    "ngptot_per_gpu": args.ngptot, "nlev": nlev, "nproma": args.nproma,
                    "parallelism": f"columns sharded over {world} GPU(s), no data-path collective",
                    "device": device_info(torch, dev),
