@@ -53,7 +53,8 @@ int read_any(cloudsc2_file* f, const char* name, hid_t memtype, void* buf, long 
   return rc;
 }
 
-int write_any(cloudsc2_file* f, const char* name, hid_t memtype, int ndims, const long long* dims, const void* buf) {
+// `filetype` is what the dataset is stored as: reals are always IEEE doubles in the file, whatever the caller holds
+int write_any(cloudsc2_file* f, const char* name, hid_t memtype, hid_t filetype, int ndims, const long long* dims, const void* buf) {
   if (!f || !name || !buf || !dims) return io_fail(CLOUDSC2_EINVAL, "NULL argument");
   if (!f->writable) return io_fail(CLOUDSC2_EINVAL, "file was opened read-only");
   if (ndims < 1 || ndims > 4) return io_fail(CLOUDSC2_EINVAL, "1..4 dimensions supported");
@@ -63,7 +64,7 @@ int write_any(cloudsc2_file* f, const char* name, hid_t memtype, int ndims, cons
     h[i] = (hsize_t)dims[i];
   }
   hid_t sp = H5Screate_simple(ndims, h, nullptr);
-  hid_t d = H5Dcreate2(f->id, name, memtype, sp, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+  hid_t d = H5Dcreate2(f->id, name, filetype, sp, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
   int rc = 0;
   if (d < 0) rc = io_fail(CLOUDSC2_EIO, std::string("cannot create dataset ") + name);
   else if (H5Dwrite(d, memtype, H5S_ALL, H5S_ALL, H5P_DEFAULT, buf) < 0) rc = io_fail(CLOUDSC2_EIO, std::string("H5Dwrite failed for ") + name);
@@ -146,10 +147,17 @@ int cloudsc2_file_read_i32(cloudsc2_file* f, const char* name, int* buf, long lo
   return read_any(f, name, H5T_NATIVE_INT, buf, count);
 }
 int cloudsc2_file_write_f64(cloudsc2_file* f, const char* name, int ndims, const long long* dims, const double* buf) {
-  return write_any(f, name, H5T_NATIVE_DOUBLE, ndims, dims, buf);
+  return write_any(f, name, H5T_NATIVE_DOUBLE, H5T_NATIVE_DOUBLE, ndims, dims, buf);
 }
 int cloudsc2_file_write_i32(cloudsc2_file* f, const char* name, int ndims, const long long* dims, const int* buf) {
-  return write_any(f, name, H5T_NATIVE_INT, ndims, dims, buf);
+  return write_any(f, name, H5T_NATIVE_INT, H5T_NATIVE_INT, ndims, dims, buf);
+}
+// fp32 callers (JPRB = fp32 builds): HDF5 converts between the fp64 file data and the fp32 buffer
+int cloudsc2_file_read_f32(cloudsc2_file* f, const char* name, float* buf, long long count) {
+  return read_any(f, name, H5T_NATIVE_FLOAT, buf, count);
+}
+int cloudsc2_file_write_f32(cloudsc2_file* f, const char* name, int ndims, const long long* dims, const float* buf) {
+  return write_any(f, name, H5T_NATIVE_FLOAT, H5T_NATIVE_DOUBLE, ndims, dims, buf);
 }
 
 int cloudsc2_file_read_params(cloudsc2_file* f, cloudsc2_params* prm, double* ptsphy) {

@@ -46,7 +46,7 @@ CONTAINS
 
     CALL CLOUDSC2_FILL_PARAMS(PRM, NLEV, LDRAIN1D)
     CALL SYSTEM_CLOCK(ICLK0, IRATE)
-    IRC = CLOUDSC2_TL_TAYLOR_RUN(PRM, NPROMA, NLEV, NGPTOT, PTSPHY, &
+    IRC = CLOUDSC2_TL_TAYLOR_RUN(PRM, NPROMA, NLEV, NGPTOT, REAL(PTSPHY,C_DOUBLE), &
      & C_LOC(PT), C_LOC(PQ), CLOUDSC2_STATE_BASE(TENDENCY_CML, NPROMA, NLEV, 'TENDENCY_CML'), &
      & CLOUDSC2_STATE_BASE(TENDENCY_LOC, NPROMA, NLEV, 'TENDENCY_LOC'), &
      & C_LOC(PAP), C_LOC(PAPH), C_LOC(PLU), C_LOC(PLUDE), C_LOC(PMFU), C_LOC(PMFD), C_LOC(PA), C_LOC(PCLV), &

@@ -38,6 +38,10 @@ int cloudsc2_file_read_i32(cloudsc2_file* f, const char* name, int* buf, long lo
 /* WRITE_SCALAR / WRITE_ARRAY: dims in C order, native double / int32 */
 int cloudsc2_file_write_f64(cloudsc2_file* f, const char* name, int ndims, const long long* dims, const double* buf);
 int cloudsc2_file_write_i32(cloudsc2_file* f, const char* name, int ndims, const long long* dims, const int* buf);
+/* The same for fp32 callers (JPRB = fp32, the reference's -DSINGLE build): the file data stay IEEE doubles, HDF5
+ * converts to/from the fp32 buffer -- what LOAD_ARRAY does when JPRB is single (file_io_mod.F90) */
+int cloudsc2_file_read_f32(cloudsc2_file* f, const char* name, float* buf, long long count);
+int cloudsc2_file_write_f32(cloudsc2_file* f, const char* name, int ndims, const long long* dims, const float* buf);
 
 /* The constants CLOUDSC2 / TL / AD read (YOMCST, YOETHF, YRECLDP, YREPHLI) + PTSPHY + KLEV from an input file, as
  * the four *_LOAD_PARAMETERS routines + CLOUDSC2_ARRAY_STATE_LOAD do.  What the mains set afterwards is applied

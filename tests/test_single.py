@@ -49,3 +49,24 @@ def test_single_column_code_on_host():
 def test_single_kernels_on_gpu():
     out = _child("gpu", 900)
     assert "driver-level NL == kernel-level NL" in out and "TEST OK" in out
+
+
+@pytest.mark.gpu
+def test_single_fortran_mains(tmp_path):
+    """fortran/build_sp: the drivers with the reference's signatures compiled with -DSINGLE (JPRB = fp32) against
+    libcloudsc2_hip_sp.so.  The NL main runs and reports; the adjoint test passes in fp32 (its dot products are
+    accumulated in fp64 on the device -- the reference's own -DSINGLE binary accumulates them in fp32 and fails its
+    test by 3e9 eps); the Taylor test stops with "TL is totally wrong" exactly where the reference's -DSINGLE binary
+    does (lambda = 1e-10 vanishes in fp32, cloudsc_driver_tl_mod.F90:247-249)."""
+    bld = os.path.join(ROOT, "dwarf_p_cloudsc2_tl_ad_amd", "fortran", "build_sp")
+    if not os.path.exists(os.path.join(bld, "dwarf-cloudsc2-nl")):
+        pytest.fail("fortran/build_sp missing: run __graft_entry__.build()")
+    run = lambda exe, *a: subprocess.run([os.path.join(bld, exe), *map(str, a)], capture_output=True, text=True,  # noqa: E731
+                                         timeout=300, cwd=tmp_path)
+    r = run("dwarf-cloudsc2-nl", 4, 16000, 32)
+    assert r.returncode == 0 and "NGPBLKS=500" in r.stderr, r.stdout + r.stderr
+    assert "PFPLSL" in r.stdout
+    r = run("dwarf-cloudsc2-ad", 1, 100, 100)
+    assert r.returncode == 0 and "TEST OK" in r.stdout, r.stdout + r.stderr
+    r = run("dwarf-cloudsc2-tl", 1, 100, 1)
+    assert "TL is totally wrong" in (r.stdout + r.stderr), r.stdout + r.stderr
