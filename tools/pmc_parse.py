@@ -31,14 +31,15 @@ def per_kernel(dirname, counter):
 
 def main():
     fetch_dir, write_dir, ngptot = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    rb = int(sys.argv[4]) if len(sys.argv) > 4 else 8  # bytes per real: 4 for the fp32 library (CLOUDSC2_PRECISION=single)
     nlev = 137
     fetch, nf = per_kernel(fetch_dir, "FETCH_SIZE")
     write, nw = per_kernel(write_dir, "WRITE_SIZE")
-    plane = ngptot * nlev * 8
+    plane = ngptot * nlev * rb
     cal_r = (2 * plane) / (fetch["satur"] * 1024)
     cal_w = (1 * plane) / (write["satur"] * 1024)
-    algo = {"nl": 28536, "tl": 57072, "ad": 85608 + 2 * 8 * nlev}  # bytes per column, DESIGN.md
-    out = {"ngptot": ngptot, "unit": "bytes per launch", "calibration": {"kernel": "satur_kernel (8 B/lane, 2 planes in, 1 out)",
+    algo = {"nl": 28536 * rb // 8, "tl": 57072 * rb // 8, "ad": (85608 + 2 * 8 * nlev) * rb // 8}  # bytes per column, DESIGN.md
+    out = {"ngptot": ngptot, "real_bytes": rb, "unit": "bytes per launch", "calibration": {"kernel": f"satur_kernel ({rb} B/lane, 2 planes in, 1 out)",
            "read_factor": cal_r, "write_factor": cal_w, "raw_fetch_kib": fetch["satur"], "raw_write_kib": write["satur"]},
            "dispatches": {"fetch": nf, "write": nw}, "kernels": {}}
     for k in ("nl", "tl", "ad"):
