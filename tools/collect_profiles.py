@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Copy the judged summaries of an evidence session (tools/evidence.sh / evidence_sp.sh) from gpurun_out/TAG into
+profiles/ under PREFIX:   python tools/collect_profiles.py gpurun_out/r01_k r01_k"""
+import glob
+import json
+import os
+import shutil
+import sys
+
+src, prefix = sys.argv[1], sys.argv[2]
+dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+cp = lambda a, b: shutil.copy(os.path.join(src, a), os.path.join(dst, f"{prefix}_{b}"))  # noqa: E731
+for n in (160000, 1048576):
+    cp(f"pmc_traffic_{n}.json", f"{n}_pmc_traffic.json")
+cp("bench_default.json", "bench_default.json")
+cp("bench_prof.json", "bench_under_rocprof.json")
+cp("bench_prof_timed_region.json", "bench_under_rocprof_timed_region.json")
+shutil.copy(glob.glob(os.path.join(src, "prof", "*", "*kernel_stats.csv"))[0], os.path.join(dst, f"{prefix}_bench_kernel_stats.csv"))
+for opt in ("rocm_smi_during_bench.txt", "single_checks_gpu.log"):
+    if os.path.exists(os.path.join(src, opt)):
+        cp(opt, opt)
+raw = os.path.join(dst, f"{prefix}_pmc_raw")
+os.makedirs(raw, exist_ok=True)
+for n in (160000, 1048576):
+    for w in ("fetch", "write"):
+        shutil.copy(glob.glob(os.path.join(src, f"pmc_{w}_{n}", "*", "*counter_collection.csv"))[0],
+                    os.path.join(raw, f"{w}_{n}_counter_collection.csv"))
+out = {}
+for k in ("nl", "tl", "ad"):
+    for n in (160000, 1048576):
+        d = json.load(open(os.path.join(src, f"bench_{k}_{n}.json")))
+        out[f"{k}_{n}"] = {"ms_per_step": d["ms_per_step"], "value": d["value"], "dtype": d["dtype"], "roofline": d["roofline"],
+                           "placement": d["config"]["placement"]}
+        print(prefix, k, n, round(d["roofline"]["kernel_ms_avg"], 3), "ms", round(100 * d["roofline"]["frac"], 1), "%", "%.3e" % d["value"])
+json.dump(out, open(os.path.join(dst, f"{prefix}_bench_all_kernels.json"), "w"), indent=1)
