@@ -136,3 +136,48 @@ def test_oracle_driver_equals_reference_driver(oracle):
     oracle.lib.oracle_driver_nl(2, 32, b.nlev, 230, b.ptsphy, *[x.ctypes.data_as(dp) for x in b.driver_arrays()])
     for n in a.outputs():
         assert np.array_equal(a.outputs()[n], b.outputs()[n]), n
+
+
+PY_REF = "/root/reference/src/cloudsc2_nl_gt4py/cloudsc2_py.py"
+
+
+@pytest.mark.skipif(not os.path.exists(PY_REF), reason="the reference checkout (its numpy restatement of SATUR + CLOUDSC2) is not here")
+def test_oracle_equals_the_references_python_restatement(oracle):
+    """A third, independent pin of the oracle: the reference's own numpy restatement of SATUR + CLOUDSC2
+    (src/cloudsc2_nl_gt4py/cloudsc2_py.py, imported from the read-only checkout, numpy + math only, LEVAPLS2 hard-wired
+    off) on synthetic columns -- agreement to rounding with the C restatement the GPU path is checked against."""
+    import importlib.util
+    import types
+
+    spec = importlib.util.spec_from_file_location("_ref_cloudsc2_py", PY_REF)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+
+    tab = c2.synthetic_table()
+    ncol = 24
+    tab = {k: (np.ascontiguousarray(v[:, :ncol]) if isinstance(v, np.ndarray) else v) for k, v in tab.items()}
+    prm = make_params(tab)
+    set_lib_params(oracle, prm)
+    st = c2.state_from_table(tab, ncol, ncol, real=np.float64)
+    nlev = st.nlev
+    ns = types.SimpleNamespace
+    cst = ns(rg=prm.rg, rd=prm.rd, rcpd=prm.rcpd, retv=prm.retv, rlvtt=prm.rlvtt, rlstt=prm.rlstt, rlmlt=prm.rlmlt, rtt=prm.rtt)
+    ethf = ns(r2es=prm.r2es, r3les=prm.r3les, r3ies=prm.r3ies, r4les=prm.r4les, r4ies=prm.r4ies, r5les=prm.r5les,
+              r5ies=prm.r5ies, r5alvcp=prm.r5alvcp, r5alscp=prm.r5alscp, ralvdcp=prm.ralvdcp, ralsdcp=prm.ralsdcp,
+              rtwat=prm.rtwat, rtice=prm.rtice, rtwat_rtice_r=prm.rtwat_rtice_r, rvtmp2=prm.rvtmp2)
+    ecldp = ns(rclcrit=prm.rclcrit, rkconv=prm.rkconv, rlmin=prm.rlmin, rpecons=prm.rpecons)
+    ecld = ns(ceta=prm.ceta_array())
+    ephli = ns(lphylin=True, rlptrc=prm.rlptrc)
+
+    inp = refcall.block_inputs(st, 0)
+    qs_py = np.zeros((nlev, ncol))
+    mod.satur(1, ncol, ncol, 1, nlev, True, inp["pap"], inp["t"], qs_py, 2, ethf, cst)
+    qs = oracle.satur(inp["pap"], inp["t"])
+    assert relerr(qs, qs_py) <= ORACLE_TOL
+    inp["qsat"] = qs
+    want = oracle.cloudsc2(st.ptsphy, inp)
+    out = refcall.new_outputs(nlev, ncol)
+    a = refcall.kernel_arg_order({k: v.copy() for k, v in inp.items()}, out)
+    mod.cloudsc2_py(1, ncol, ncol, 1, nlev, False, st.ptsphy, *a, ecldp, ecld, cst, ethf, ephli)
+    for n in want:
+        assert relerr(want[n], out[n]) <= 5e-13, n
