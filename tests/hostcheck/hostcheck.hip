@@ -25,9 +25,19 @@ template <unsigned F> struct HcNl {
     if constexpr (!((F & C2F_PERT) && (F & C2F_CKPT))) nl_column<F>(gc, a);
   }
 };
-template <unsigned F> struct HcTl { static void run(long long gc, const TlArgs* a) { tl_column<F>(gc, a); } };
+// only the flag words the launchers can produce are instantiated (TL: QSAT|PRECISE|EVAP|TRAJ|OFF32, AD: no TRAJ)
+template <unsigned F> struct HcTl {
+  static void run(long long gc, const TlArgs* a) {
+    if constexpr ((F & ~(C2F_QSAT | C2F_PRECISE | C2F_EVAP | C2F_TRAJ | C2F_OFF32)) == 0) tl_column<F>(gc, a);
+  }
+};
 template <unsigned F> struct HcAd {
-  static void run(long long gc, const AdArgs* a) { nl_column<F | C2F_CKPT>(gc, &a->nl); ad_reverse_column<F>(gc, a); }
+  static void run(long long gc, const AdArgs* a) {
+    if constexpr ((F & ~(C2F_QSAT | C2F_PRECISE | C2F_EVAP | C2F_OFF32)) == 0) {
+      nl_column<F | C2F_CKPT>(gc, &a->nl);
+      ad_reverse_column<F>(gc, a);
+    }
+  }
 };
 
 // same derivation as get_tables() in cloudsc2_kernels.hip
@@ -72,7 +82,7 @@ static int g_hc_off32 = 0;
 extern "C" {
 
 void hostcheck_set_precise(int p) { g_hc_precise = p; }
-void hostcheck_set_off32(int v) { g_hc_off32 = v; }  // NL: 32-bit byte offsets (C2F_OFF32)
+void hostcheck_set_off32(int v) { g_hc_off32 = v; }  // 32-bit byte offsets (C2F_OFF32) in all three sweeps
 
 int hostcheck_satur(const cloudsc2_params* prm, int nproma, int nlev, int ngptot, cloudsc2_field pap, cloudsc2_field t,
                     cloudsc2_field qsat) {
@@ -110,8 +120,9 @@ int hostcheck_tl(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev
   a.tab = &tab;
   a.s = Strides{0, 0, 0, 0, 0}; a.sp = Strides{0, 0, 0, 0, 0};
   hc_in(*in, a.s, a.in); hc_out(*out, a.s, a.out); hc_in(*din, a.sp, a.din); hc_out(*dout, a.sp, a.dout);
-  unsigned f = (in->qsat.ptr ? C2F_QSAT : 0u) | C2F_TRAJ | (g_hc_precise ? C2F_PRECISE : 0u) | (a.c.evap ? C2F_EVAP : 0u);
-  for (long long gc = 0; gc < a.g.ncols_pad; ++gc) hc_dispatch<HcTl, 16>(f, gc, &a);
+  unsigned f = (in->qsat.ptr ? C2F_QSAT : 0u) | C2F_TRAJ | (g_hc_precise ? C2F_PRECISE : 0u) | (a.c.evap ? C2F_EVAP : 0u) |
+               (g_hc_off32 ? C2F_OFF32 : 0u);
+  for (long long gc = 0; gc < a.g.ncols_pad; ++gc) hc_dispatch<HcTl, 64>(f, gc, &a);
   return 0;
 }
 
@@ -130,8 +141,9 @@ int hostcheck_ad(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev
   a.ain.mfd = ain->mfd.ptr; a.ain.gt = ain->gtent.ptr; a.ain.gq = ain->gtenq.ptr; a.ain.gl = ain->gtenl.ptr;
   a.ain.gi = ain->gteni.ptr; a.ain.supsat = ain->supsat.ptr;
   a.nl.zero_plane = nullptr; a.nl.zero_stride = 0; a.nl.lam = 0.0; a.nl.ckpt = scratch;
-  unsigned f = (in->qsat.ptr ? C2F_QSAT : 0u) | (g_hc_precise ? C2F_PRECISE : 0u) | (a.nl.c.evap ? C2F_EVAP : 0u);
-  for (long long gc = 0; gc < a.nl.g.ncols_pad; ++gc) hc_dispatch<HcAd, 8>(f, gc, &a);
+  unsigned f = (in->qsat.ptr ? C2F_QSAT : 0u) | (g_hc_precise ? C2F_PRECISE : 0u) | (a.nl.c.evap ? C2F_EVAP : 0u) |
+               (g_hc_off32 ? C2F_OFF32 : 0u);
+  for (long long gc = 0; gc < a.nl.g.ncols_pad; ++gc) hc_dispatch<HcAd, 64>(f, gc, &a);
   return 0;
 }
 

@@ -109,6 +109,29 @@ def test_tl_ad_columns(oracle, flags, nlev):
     assert hc.hostcheck_ad(C.byref(prm), st.ptsphy, nproma, nlev, ngptot, C.byref(i2), C.byref(o2), C.byref(ai), C.byref(ao),
                            scratch.ctypes.data) == 0
 
+    # the 32-bit byte-offset variants of the TL and AD sweeps (C2F_OFF32) give the same bits, and the checkpoint stores
+    # stay inside the scratch plane (guard block behind it)
+    hc.hostcheck_set_off32(1)
+    try:
+        got3 = st.copy()
+        i3, o3 = host_traj_blocks(got3, qsat)
+        tl3 = flat_fields("out", nb, nlev, nproma)
+        di3, do3 = flat_block("in", inc), flat_block("out", tl3)
+        assert hc.hostcheck_tl(C.byref(prm), st.ptsphy, nproma, nlev, ngptot, C.byref(i3), C.byref(o3), C.byref(di3), C.byref(do3)) == 0
+        x3 = flat_fields("in", nb, nlev, nproma)
+        y3 = {n: a.copy() for n, a in tl3.items()}
+        guard = np.full((nb + 1, nlev, nproma), 7.0)
+        ai3, ao3 = flat_block("in", x3), flat_block("out", y3)
+        assert hc.hostcheck_ad(C.byref(prm), st.ptsphy, nproma, nlev, ngptot, C.byref(i3), C.byref(o3), C.byref(ai3), C.byref(ao3),
+                               guard.ctypes.data) == 0
+    finally:
+        hc.hostcheck_set_off32(0)
+    assert np.all(guard[nb] == 7.0)
+    for n in tl:
+        assert np.array_equal(tl[n], tl3[n]), ("off32 tl", n)
+    for n in x:
+        assert np.array_equal(x[n], x3[n]), ("off32 ad", n)
+
     ld = bool(flags.get("ldrain1d", False))
     for ibl in range(nb):
         icend = min(nproma, ngptot - ibl * nproma)
