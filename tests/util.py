@@ -21,6 +21,8 @@ HOSTCHECK_LIB = os.path.join(HOSTCHECK_DIR, "libhostcheck_sp.so" if B.SINGLE els
 
 
 def build_hostcheck() -> str:
+    if os.environ.get("CLOUDSC2_HOSTCHECK_LIB"):  # a differently built copy, e.g. the AddressSanitizer build of test_sanitize.py
+        return os.environ["CLOUDSC2_HOSTCHECK_LIB"]
     src = os.path.join(HOSTCHECK_DIR, "hostcheck.hip")
     deps = [src] + [os.path.join(ROOT, "dwarf_p_cloudsc2_tl_ad_amd", "csrc", f) for f in ("cloudsc2_level.hpp", "cloudsc2_column.hpp")]
     if (not os.path.exists(HOSTCHECK_LIB)) or any(os.path.getmtime(d) > os.path.getmtime(HOSTCHECK_LIB) for d in deps):
