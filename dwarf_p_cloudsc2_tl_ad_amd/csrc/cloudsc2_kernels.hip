@@ -157,8 +157,13 @@ __global__ void __launch_bounds__(kBlock, (C2_NL_WAVES > 0) ? C2_NL_WAVES : ((F 
   C2_KERNEL_BODY((nl_column<F>(global_column(), kernarg<NlArgs>())));
 }
 
+// fp32 only: the TL variants with 32-bit offsets and without the evaporation branch need 173 VGPRs; held to 168 (3 waves
+// per SIMD) they spill at most 7 dwords, and all 2500 waves of a 160 000-column launch are resident at once instead of
+// 2048 + 452 (0.94 -> 0.88 ms).  Every other TL variant, and the fp64 ones, spill heavily below what they ask for.
 template <unsigned F>
-__global__ void C2_BOUNDS(C2_TL_WAVES) tl_kernel(TlArgs args) {
+__global__ void __launch_bounds__(kBlock, (C2_TL_WAVES > 0) ? C2_TL_WAVES
+                                          : (sizeof(real_t) == 4 && (F & C2F_OFF32) && !(F & C2F_EVAP)) ? 3 : 1)
+tl_kernel(TlArgs args) {
   C2_KERNEL_BODY((tl_column<F>(global_column(), kernarg<TlArgs>())));
 }
 
