@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--nproma", type=int, default=128)
     ap.add_argument("--kernel", choices=["nl", "tl", "ad"], default="nl")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-companions", action="store_true", help="skip the short TL and AD timings appended to the NL line")
     ap.add_argument("--precision", choices=["double", "single"], default=os.environ.get("CLOUDSC2_PRECISION", "double"),
                     help="single = the fp32 library (the reference's -DSINGLE build); the headline metric is double")
     ap.add_argument("--levapls2", action="store_true", help="switch the evaporation branch on (off in every shipped config)")
@@ -168,7 +169,7 @@ def main():
         ds.tl(prm, inc, dout, stream)
         scratch = ds.new_scratch()
         # + carry checkpoint plane (write + read)
-        return (lambda: ds.ad(prm, inc, dout, scratch, stream)), c2.bytes_per_column(nlev, "ad") + 2 * 8 * nlev, \
+        return (lambda: ds.ad(prm, inc, dout, scratch, stream)), c2.bytes_per_column(nlev, "ad") + 2 * c2.binding.REAL_BYTES * nlev, \
             "ad_kernel<C2F_QSAT> (CLOUDSC2AD: trajectory pass + reverse pass)", (ds, inc, dout, scratch)
 
     # Where in the 288 GB of HBM the state lives decides up to 17 % of the kernel time (stable for the life of an allocation,
@@ -263,6 +264,41 @@ def main():
                                  "chosen": best}},
         "roofline": roofline,
     }
+    if rank == 0 and world == 1 and args.kernel == "nl" and not args.no_companions:
+        # BASELINE.json's metric names NL/TL/AD: short timings of the other two kernels on the state just measured (their
+        # own perturbation / adjoint arrays are fresh allocations without a placement search, so dedicated
+        # `--kernel tl|ad` runs measure up to a few % faster).  Outside the timed region; never part of `value`.
+        comp = {}
+        try:
+            ds = keep
+            for kind in ("tl", "ad"):
+                prm_k = c2.default_params(c2.ceta_from_table(tab), lregcl=(kind == "ad"), levapls2=args.levapls2)
+                ds.satur(prm_k, stream)
+                inc = ds.increments(zero_supsat=(kind == "ad"))
+                dout = c2.FlatFields("out", ds.nb, ds.nlev, ds.nproma, dev)
+                if kind == "tl":
+                    fn = lambda: ds.tl(prm_k, inc, dout, stream)  # noqa: E731
+                    kb = c2.bytes_per_column(nlev, "tl")
+                else:
+                    ds.tl(prm_k, inc, dout, stream)
+                    scratch = ds.new_scratch()
+                    fn = lambda: ds.ad(prm_k, inc, dout, scratch, stream)  # noqa: E731
+                    kb = c2.bytes_per_column(nlev, "ad") + 2 * c2.binding.REAL_BYTES * nlev
+                for _ in range(10):
+                    fn()
+                cev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+                for a, b in cev:
+                    a.record(stream)
+                    fn()
+                    b.record(stream)
+                torch.cuda.synchronize(dev)
+                ms = float(np.median([a.elapsed_time(b) for a, b in cev]))
+                comp[kind] = {"kernel_ms": ms, "columns_per_s": args.ngptot / (ms * 1e-3), "bytes_per_column": kb,
+                              "frac_of_hbm_peak": kb * args.ngptot / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                del inc, dout
+        except Exception as e:  # noqa: BLE001  (never let the companions break the headline line)
+            comp["error"] = repr(e)
+        out["companion_kernels"] = comp
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.kernel == "nl":
         cb = cpu_baseline(tab, prm, 32, args.ngptot)
         if cb:
