@@ -298,6 +298,8 @@ def main():
                 del inc, dout
         except Exception as e:  # noqa: BLE001  (never let the companions break the headline line)
             comp["error"] = repr(e)
+        comp["note"] = ("TL and AD on the NL state of this run; their perturbation/adjoint arrays are fresh allocations without a "
+                        "placement search: `bench.py --kernel tl|ad` (profiles/*_bench_all_kernels.json) measures 5-10 % faster")
         out["companion_kernels"] = comp
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.kernel == "nl":
         cb = cpu_baseline(tab, prm, 32, args.ngptot)
