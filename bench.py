@@ -265,41 +265,27 @@ def main():
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and args.kernel == "nl" and not args.no_companions:
-        # BASELINE.json's metric names NL/TL/AD: short timings of the other two kernels on the state just measured (their
-        # own perturbation / adjoint arrays are fresh allocations without a placement search, so dedicated
-        # `--kernel tl|ad` runs measure up to a few % faster).  Outside the timed region; never part of `value`.
+        # BASELINE.json's metric names NL/TL/AD: the same bench for the other two kernels, each in a child process with its
+        # own placement search, after this process has given its device memory back.  Outside the timed region, never
+        # part of `value`; `--no-companions` skips it.
+        import subprocess
+
+        del cands, step, keep, spacers, w
+        torch.cuda.empty_cache()
         comp = {}
-        try:
-            ds = keep
-            for kind in ("tl", "ad"):
-                prm_k = c2.default_params(c2.ceta_from_table(tab), lregcl=(kind == "ad"), levapls2=args.levapls2)
-                ds.satur(prm_k, stream)
-                inc = ds.increments(zero_supsat=(kind == "ad"))
-                dout = c2.FlatFields("out", ds.nb, ds.nlev, ds.nproma, dev)
-                if kind == "tl":
-                    fn = lambda: ds.tl(prm_k, inc, dout, stream)  # noqa: E731
-                    kb = c2.bytes_per_column(nlev, "tl")
-                else:
-                    ds.tl(prm_k, inc, dout, stream)
-                    scratch = ds.new_scratch()
-                    fn = lambda: ds.ad(prm_k, inc, dout, scratch, stream)  # noqa: E731
-                    kb = c2.bytes_per_column(nlev, "ad") + 2 * c2.binding.REAL_BYTES * nlev
-                for _ in range(10):
-                    fn()
-                cev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
-                for a, b in cev:
-                    a.record(stream)
-                    fn()
-                    b.record(stream)
-                torch.cuda.synchronize(dev)
-                ms = float(np.median([a.elapsed_time(b) for a, b in cev]))
-                comp[kind] = {"kernel_ms": ms, "columns_per_s": args.ngptot / (ms * 1e-3), "bytes_per_column": kb,
-                              "frac_of_hbm_peak": kb * args.ngptot / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-                del inc, dout
-        except Exception as e:  # noqa: BLE001  (never let the companions break the headline line)
-            comp["error"] = repr(e)
-        comp["note"] = ("TL and AD on the NL state of this run; their perturbation/adjoint arrays are fresh allocations without a "
-                        "placement search: `bench.py --kernel tl|ad` (profiles/*_bench_all_kernels.json) measures 5-10 % faster")
+        for kind in ("tl", "ad"):
+            cmd = [sys.executable, os.path.abspath(__file__), "--kernel", kind, "--steps", "30", "--warmup", "5", "--no-cpu-baseline",
+                   "--ngptot", str(args.ngptot), "--nproma", str(args.nproma), "--precision", args.precision,
+                   "--placement-regions", args.placement_regions] + (["--levapls2"] if args.levapls2 else [])
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                d = json.loads(r.stdout.strip().splitlines()[-1])
+                comp[kind] = {"value": d["value"], "unit": d["unit"], "kernel_ms_avg": d["roofline"]["kernel_ms_avg"],
+                              "bytes_per_column": d["roofline"]["bytes_per_column"], "frac": d["roofline"]["frac"],
+                              "traffic": d["roofline"]["traffic"], "kernel": d["roofline"]["kernel"],
+                              "placement_ms": d["config"]["placement"]["kernel_ms_per_candidate"]}
+            except Exception as e:  # noqa: BLE001  (never let the companions break the headline line)
+                comp[kind] = {"error": repr(e)}
         out["companion_kernels"] = comp
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.kernel == "nl":
         cb = cpu_baseline(tab, prm, 32, args.ngptot)

@@ -11,7 +11,7 @@ rocm-smi --showproductname --showclocks --showpower --showperflevel --showmemven
 smi_pid=$!
 timeout -k 10 600 python bench.py > $out/bench_default.json 2> $out/bench_default.err && cat $out/bench_default.json || exit 1
 wait $smi_pid
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 bench.py --no-cpu-baseline > $out/bench_prof.json 2> $out/bench_prof.err || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 bench.py --no-cpu-baseline --no-companions > $out/bench_prof.json 2> $out/bench_prof.err || exit 1
 # rocprofv3's average covers the placement candidates too; the timed region is the last 300 dispatches of the hot kernel
 python tools/trace_timed_region.py $out/prof/*/*_kernel_trace.csv nl_kernel 300 > $out/bench_prof_timed_region.json
 for n in 160000 1048576; do
