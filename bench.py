@@ -9,6 +9,10 @@ Before the measurement the state is placed: which physical HBM an allocation lan
 time on this part, so candidates are allocated in several regions of the 288 GB (--placement-regions),
 each is timed with ten launches, and the fastest is used for the W warm-up and K timed steps.  Every candidate's
 time is in config.placement; --placement-regions 0 takes whatever the first allocation gets.
+
+The line also carries `cpu_baseline` (the reference on the host cores, rank 0 at N=1) and, at N=1, `companion_kernels`:
+the same bench for TL and AD, each run as a child process after the NL measurement (BASELINE.json's metric names all
+three kernels); neither is inside the timed region.
 """
 from __future__ import annotations
 
