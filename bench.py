@@ -120,7 +120,7 @@ def device_info(torch, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=600)
+    ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--ngptot", type=int, default=160000, help="columns per GPU")
     ap.add_argument("--nproma", type=int, default=128)
@@ -130,7 +130,7 @@ def main():
     ap.add_argument("--precision", choices=["double", "single"], default=os.environ.get("CLOUDSC2_PRECISION", "double"),
                     help="single = the fp32 library (the reference's -DSINGLE build); the headline metric is double")
     ap.add_argument("--levapls2", action="store_true", help="switch the evaporation branch on (off in every shipped config)")
-    ap.add_argument("--placement-regions", default="0,14,28,42,56,70,84,98,112,126,140,154,168,182,196,210",
+    ap.add_argument("--placement-regions", default="0,9,18,27,36,45,54,63,72,81,90,99,108,117,126,135,144,153,162,171,180,189,198,207",
                     help="GiB offsets in HBM at which candidate placements of the state are timed before the measurement "
                          "(the fastest is used; '0' = just allocate)")
     args = ap.parse_args()

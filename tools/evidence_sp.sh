@@ -6,7 +6,7 @@ export CLOUDSC2_PRECISION=single
 timeout -k 10 300 python tests/single_checks.py gpu > $out/single_checks_gpu.log 2>&1 && tail -1 $out/single_checks_gpu.log || { tail -5 $out/single_checks_gpu.log; exit 1; }
 timeout -k 10 600 python bench.py > $out/bench_default.json 2> $out/bench_default.err && cat $out/bench_default.json || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 bench.py --no-cpu-baseline --no-companions > $out/bench_prof.json 2> $out/bench_prof.err || exit 1
-python tools/trace_timed_region.py $out/prof/*/*_kernel_trace.csv nl_kernel 600 > $out/bench_prof_timed_region.json
+python tools/trace_timed_region.py $out/prof/*/*_kernel_trace.csv nl_kernel 1000 > $out/bench_prof_timed_region.json
 for n in 160000 1048576; do
   PMC_NGPTOT=$n timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_$n -- python3 tools/pmc_workload.py > $out/pmc_fetch_$n.log 2>&1 || exit 1
   PMC_NGPTOT=$n timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write_$n -- python3 tools/pmc_workload.py > $out/pmc_write_$n.log 2>&1 || exit 1
