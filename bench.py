@@ -212,11 +212,17 @@ def main():
     step, bpc, kname, keep = cands[best]
     nlev = (keep[0] if isinstance(keep, tuple) else keep).nlev
 
+    def barrier():
+        if torch.distributed.get_backend() == "nccl":
+            torch.distributed.barrier(device_ids=[local])  # the rank's own GPU, not a guess
+        else:
+            torch.distributed.barrier()
+
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
     if world > 1:
-        torch.distributed.barrier()
+        barrier()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -226,7 +232,7 @@ def main():
         b.record(stream)
     torch.cuda.synchronize(dev)
     if world > 1:
-        torch.distributed.barrier()
+        barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
         elapsed = float(c2dist.allreduce_max([elapsed], dev)[0])  # MAX over ranks (RCCL all-reduce of one double)
