@@ -89,3 +89,16 @@ def test_state_layout_and_tiling():
     assert np.array_equal(st1.PT.transpose(0, 2, 1).reshape(-1, 137)[: b - a], cols[a:b])
     assert c2.bytes_per_column(137, "nl") == 27440 and c2.bytes_per_column(137, "tl") == 57072
     assert c2.bytes_per_column(137, "ad") == 85608
+
+
+def test_bench_cpu_baseline_leg_runs():
+    """bench.py's cpu_baseline leg (the reference, or the C port, timed on the host cores) on a small sample."""
+    import bench
+
+    from tests.util import c2
+
+    tab = c2.synthetic_table()
+    prm = c2.default_params(c2.ceta_from_table(tab))
+    cb = bench.cpu_baseline(tab, prm, 32, 2000, budget_s=0.5)
+    assert cb is not None and cb["unit"] == "columns/s" and cb["kind"] in ("reference", "port")
+    assert cb["value"] > 0 and cb["numomp4_value"] > 0 and cb["cores"] >= 1
