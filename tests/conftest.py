@@ -6,5 +6,17 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _built() -> bool:
+    pkg = os.path.join(ROOT, "dwarf_p_cloudsc2_tl_ad_amd")
+    need = [os.path.join(pkg, "csrc", "libcloudsc2_hip.so"), os.path.join(pkg, "csrc", "libcloudsc2_hip_sp.so"),
+            os.path.join(pkg, "csrc", "libcloudsc2_io.so"), os.path.join(ROOT, "oracle", "libcloudsc2_oracle.so")]
+    return all(os.path.exists(p) for p in need)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no built artefacts (they are git-ignored): build them once, as __graft_entry__.build() does
+    if not _built() and os.path.exists("/opt/rocm/bin/hipcc"):
+        import __graft_entry__
+
+        __graft_entry__.build()
