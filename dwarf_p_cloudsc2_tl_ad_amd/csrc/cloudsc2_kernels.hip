@@ -168,10 +168,19 @@ tl_kernel(TlArgs args) {
 }
 
 // C2_AD_FUSED=1: one kernel runs a column's trajectory pass and then its reverse pass (waves in the bandwidth-heavy
-// forward phase and waves in the arithmetic-heavy reverse phase share the CUs); 0: two kernels in stream order.
+// forward phase and waves in the arithmetic-heavy reverse phase share the CUs); 0: two kernels in stream order;
+// 2: both are built and launches of at most kAdSplitBelow columns take the two-kernel form.  fp64: the two forms measure
+// the same at every size (both passes need one wave per SIMD's worth of registers in the fused kernel anyway).  fp32: the
+// trajectory pass alone runs six waves per SIMD instead of the fused kernel's two, which is worth 7 % when the whole
+// launch is one round of waves (160 000 columns: 1.71 -> 1.59 ms) and nothing at 1 M columns (9.09 vs 9.17 ms).
 #ifndef C2_AD_FUSED
+#if defined(CLOUDSC2_SINGLE)
+#define C2_AD_FUSED 2
+#else
 #define C2_AD_FUSED 1
 #endif
+#endif
+constexpr long long kAdSplitBelow = 400000;
 template <unsigned F>
 __global__ void C2_BOUNDS(C2_AD_WAVES) ad_reverse_kernel(AdArgs args) {
   C2_KERNEL_BODY((ad_reverse_column<F>(global_column(), kernarg<AdArgs>())));
@@ -191,9 +200,9 @@ template <class Args> using KernelFn = void (*)(Args);
   template <unsigned... F> constexpr std::array<KernelFn<Args>, sizeof...(F)> table##_make(                        \
       std::integer_sequence<unsigned, F...>) { return {{table##_entry<F>()...}}; }                                 \
   [[maybe_unused]] const std::array<KernelFn<Args>, NF> table = table##_make(std::make_integer_sequence<unsigned, NF>{});
-C2_VARIANT_TABLE(g_nl_kernels, nl_kernel, NlArgs, 64, !((F & C2F_PERT) && (F & C2F_CKPT)) && (C2_AD_FUSED ? !(F & C2F_CKPT) : true))
+C2_VARIANT_TABLE(g_nl_kernels, nl_kernel, NlArgs, 64, !((F & C2F_PERT) && (F & C2F_CKPT)) && (C2_AD_FUSED == 1 ? !(F & C2F_CKPT) : true))
 C2_VARIANT_TABLE(g_tl_kernels, tl_kernel, TlArgs, 64, !(F & 16u))
-C2_VARIANT_TABLE(g_ad_reverse_kernels, ad_reverse_kernel, AdArgs, 64, !C2_AD_FUSED && !(F & 24u))
+C2_VARIANT_TABLE(g_ad_reverse_kernels, ad_reverse_kernel, AdArgs, 64, C2_AD_FUSED != 1 && !(F & 24u))
 C2_VARIANT_TABLE(g_ad_kernels, ad_kernel, AdArgs, 64, C2_AD_FUSED != 0 && !(F & 24u))
 
 // ---------------------------------------------------------------------------------------------------------
@@ -633,13 +642,11 @@ int cloudsc2_ad_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
   if (args.nl.c.evap) f |= C2F_EVAP;
   if (fits_off32(g, nproma, nlev, {s.full, s.half, s.cml, s.clv, s.loc, sa.full, sa.half, sa.cml, sa.clv, sa.loc,
                                   (long long)nproma * nlev /* scratch */})) f |= C2F_OFF32;
-#if C2_AD_FUSED
-  return launch_variant(g_ad_kernels[f], args, g.ncols_pad, (hipStream_t)stream);
-#else
+  const bool fused = C2_AD_FUSED == 1 || (C2_AD_FUSED == 2 && g.ncols_pad > kAdSplitBelow);
+  if (fused) return launch_variant(g_ad_kernels[f], args, g.ncols_pad, (hipStream_t)stream);
   // trajectory pass (NL kernel + carry checkpoints), then the reverse pass, in stream order
   if ((rc = launch_variant(g_nl_kernels[f | C2F_CKPT], args.nl, g.ncols_pad, (hipStream_t)stream))) return rc;
   return launch_variant(g_ad_reverse_kernels[f], args, g.ncols_pad, (hipStream_t)stream);
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------
