@@ -8,6 +8,7 @@ coalesced reads by exactly 2x for 16 B per lane; this code reads 8 B per lane, s
 calibrated on the SATUR dispatch whose byte count is known (2 planes in, 1 plane out)."""
 import csv
 import glob
+import re
 import json
 import os
 import sys
@@ -20,13 +21,25 @@ def per_kernel(dirname, counter):
             if row.get("Counter_Name") != counter:
                 continue
             name = row["Kernel_Name"]
-            key = ("satur" if "satur_kernel" in name else "nl" if "nl_kernel" in name else "tl" if "tl_kernel" in name
-                   else "ad" if "ad_kernel" in name else None)
+            m = re.search(r"nl_kernel<(\d+)u?>", name)
+            if "ad_reverse_kernel" in name:
+                key = "ad_rev"   # two-kernel form of the adjoint: reverse pass ...
+            elif m and int(m.group(1)) & 16:
+                key = "ad_fwd"   # ... and its trajectory pass (nl_kernel with C2F_CKPT)
+            else:
+                key = ("satur" if "satur_kernel" in name else "nl" if "nl_kernel" in name else "tl" if "tl_kernel" in name
+                       else "ad" if "ad_kernel" in name else None)
             if key is None:
                 continue
             acc.setdefault(key, {}).setdefault(row["Dispatch_Id"], 0.0)
             acc[key][row["Dispatch_Id"]] += float(row["Counter_Value"])
-    return {k: sum(v.values()) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
+    avg = {k: sum(v.values()) / len(v) for k, v in acc.items()}
+    cnt = {k: len(v) for k, v in acc.items()}
+    if "ad" not in avg and "ad_fwd" in avg and "ad_rev" in avg:  # one adjoint launch = one of each
+        avg["ad"] = avg.pop("ad_fwd") + avg.pop("ad_rev")
+        cnt["ad"] = cnt.pop("ad_rev")
+        cnt.pop("ad_fwd")
+    return avg, cnt
 
 
 def main():
