@@ -117,6 +117,42 @@ def device_info(torch, dev):
         return {"error": repr(e)}
 
 
+def free_port() -> int:
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(ngpus: int, argv) -> int:
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) of this same script and
+    relay rank 0's JSON line.  Runs before anything in this process has touched the GPU or imported torch; the children get
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* exactly as `python -m torch.distributed.run --nproc-per-node N` would set
+    them, so both ways of starting the bench run the same code."""
+    import subprocess
+
+    env = dict(os.environ, WORLD_SIZE=str(ngpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), LOCAL_WORLD_SIZE=str(ngpus))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL needs it)
+    procs = []
+    for r in range(ngpus):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    lines = [ln for ln in (out0 or "").splitlines() if ln.strip()]
+    if lines:
+        print(lines[-1], flush=True)
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad or not lines:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,6 +170,14 @@ def main():
                     help="GiB offsets in HBM at which candidate placements of the state are timed before the measurement "
                          "(the fastest is used; '0' = just allocate)")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:  # no launcher: become one (nothing here has touched the GPU yet)
+            raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
 
     import torch
 

@@ -47,7 +47,7 @@ class Params(C.Structure):
                 "rtwat_rticecu_r")
     _fields_ = ([(n, C.c_double) for n in _DOUBLES] +
                 [("lphylin", C.c_int), ("levapls2", C.c_int), ("lregcl", C.c_int), ("ldrain1d", C.c_int),
-                 ("nlev", C.c_int), ("reserved", C.c_int), ("ceta", C.c_double * CLOUDSC2_MAX_NLEV)])
+                 ("nlev", C.c_int), ("math_mode", C.c_int), ("ceta", C.c_double * CLOUDSC2_MAX_NLEV)])
 
     def doubles30(self) -> np.ndarray:
         """The 30 leading constants in the order oracle/ref_harness.F90 takes them."""

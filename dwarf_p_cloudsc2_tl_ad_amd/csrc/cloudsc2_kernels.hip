@@ -43,6 +43,13 @@ int initial_math_mode() {
 }
 std::atomic<int> g_precise{initial_math_mode()};
 
+// arithmetic of one call: the call's own request, else the process default (read, never written, by the launchers)
+bool precise_of(const cloudsc2_params* prm) {
+  if (prm->math_mode == 2) return true;
+  if (prm->math_mode == 1) return false;
+  return g_precise.load() != 0;
+}
+
 int fail(int code, const char* msg) {
   g_err = msg;
   return code;
@@ -88,6 +95,15 @@ int get_tables(const cloudsc2_params& p, const LevelTab** dev, int* kb0, int* kb
       *dev = e.dev; *kb0 = e.kb0; *kb1 = e.kb1;
       return 0;
     }
+  }
+  // CETA is a property of the vertical grid: a process sees one or two of them.  A caller that varies it per call would
+  // grow the cache without bound, so it is capped; an evicted table must not be freed while a launch may still read it,
+  // hence the device-wide synchronisation (rare by construction).
+  constexpr size_t kMaxTables = 16;
+  if (g_tabs.size() >= kMaxTables) {
+    HIP_TRY(hipDeviceSynchronize());
+    (void)hipFree(g_tabs.front().dev);
+    g_tabs.erase(g_tabs.begin());
   }
   TabEntry e;
   e.device = device;
@@ -447,6 +463,7 @@ int check_geom(const cloudsc2_params* prm, int nproma, int nlev, int ngptot, Geo
   if (nproma < 1 || nlev < 2 || ngptot < 1) return fail(CLOUDSC2_EINVAL, "nproma >= 1, nlev >= 2, ngptot >= 1 required");
   if (nlev > CLOUDSC2_MAX_NLEV) return fail(CLOUDSC2_EINVAL, "nlev exceeds CLOUDSC2_MAX_NLEV");
   if (prm->nlev != nlev) return fail(CLOUDSC2_EINVAL, "params.nlev does not match nlev");
+  if (prm->math_mode < 0 || prm->math_mode > 2) return fail(CLOUDSC2_EINVAL, "params.math_mode must be 0 (default), 1 (fast) or 2 (precise)");
   if (!prm->lphylin) return fail(CLOUDSC2_EINVAL, "LPHYLIN=.false. is not supported (every reference main forces .true.)");
   if (!device_ok()) return fail(CLOUDSC2_ENODEVICE, "no HIP device available (this library has no CPU path)");
   long long nblocks = ((long long)ngptot + nproma - 1) / nproma;
@@ -529,6 +546,7 @@ void cloudsc2_params_default(cloudsc2_params* p) {
   p->lregcl = 0;
   p->ldrain1d = 0;
   p->nlev = 0;
+  p->math_mode = 0;
 }
 
 int cloudsc2_satur_launch(const cloudsc2_params* prm, int nproma, int nlev, int ngptot, cloudsc2_field pap,
@@ -544,7 +562,7 @@ int cloudsc2_satur_launch(const cloudsc2_params* prm, int nproma, int nlev, int 
   args.g = g;
   args.s = Strides{pap.block_stride, 0, 0, 0, 0};
   args.pap = pap.ptr; args.t = t.ptr; args.qsat = qsat.ptr;
-  if (g_precise.load()) hipLaunchKernelGGL(satur_kernel<true>, dim3(grid_for(g.ncols_pad, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, args);
+  if (precise_of(prm)) hipLaunchKernelGGL(satur_kernel<true>, dim3(grid_for(g.ncols_pad, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, args);
   else hipLaunchKernelGGL(satur_kernel<false>, dim3(grid_for(g.ncols_pad, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, args);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -571,7 +589,7 @@ int cloudsc2_nl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
   unsigned f = 0;
   if (in->qsat.ptr) f |= C2F_QSAT;
   if (pert_lambda != 0.0) f |= C2F_PERT;
-  if (g_precise.load()) f |= C2F_PRECISE;
+  if (precise_of(prm)) f |= C2F_PRECISE;
   if (args.c.evap) f |= C2F_EVAP;
   if (fits_off32(g, nproma, nlev, {s.full, s.half, s.cml, s.clv, s.loc, (long long)zero_plane.block_stride})) f |= C2F_OFF32;
   return launch_variant(g_nl_kernels[f], args, g.ncols_pad, (hipStream_t)stream);
@@ -604,7 +622,7 @@ int cloudsc2_tl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
   unsigned f = 0;
   if (traj_in->qsat.ptr) f |= C2F_QSAT;
   if (store_traj) f |= C2F_TRAJ;
-  if (g_precise.load()) f |= C2F_PRECISE;
+  if (precise_of(prm)) f |= C2F_PRECISE;
   if (args.c.evap) f |= C2F_EVAP;
   if (fits_off32(g, nproma, nlev, {s.full, s.half, s.cml, s.clv, s.loc, sp.full, sp.half, sp.cml, sp.clv, sp.loc})) f |= C2F_OFF32;
   return launch_variant(g_tl_kernels[f], args, g.ncols_pad, (hipStream_t)stream);
@@ -638,7 +656,7 @@ int cloudsc2_ad_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
   args.sa = sa; args.ain = aip; args.aout = aop;
   unsigned f = 0;
   if (traj_in->qsat.ptr) f |= C2F_QSAT;
-  if (g_precise.load()) f |= C2F_PRECISE;
+  if (precise_of(prm)) f |= C2F_PRECISE;
   if (args.nl.c.evap) f |= C2F_EVAP;
   if (fits_off32(g, nproma, nlev, {s.full, s.half, s.cml, s.clv, s.loc, sa.full, sa.half, sa.cml, sa.clv, sa.loc,
                                   (long long)nproma * nlev /* scratch */})) f |= C2F_OFF32;

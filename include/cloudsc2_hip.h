@@ -54,7 +54,7 @@ typedef struct cloudsc2_params {
   int lregcl;    /* TL/AD regularisation (cloudsc2tl.F90:575,657,754,794,998) */
   int ldrain1d;
   int nlev;
-  int reserved;
+  int math_mode; /* arithmetic of THIS call: 0 = the process default (cloudsc2_set_math_mode), 1 = fast, 2 = precise */
   double ceta[CLOUDSC2_MAX_NLEV];
 } cloudsc2_params;
 
@@ -68,11 +68,14 @@ int cloudsc2_device_available(void);
 /* sizeof(cloudsc2_real) of THIS build of the library: 8, or 4 for the -DCLOUDSC2_SINGLE build. */
 int cloudsc2_real_bytes(void);
 
-/* Arithmetic of the kernels (process-wide; initial value from the environment variable CLOUDSC2_MATH=fast|precise).
- *   0 fast (default): quotients on shared / batch-inverted v_rcp_f64 reciprocals refined by two Newton steps, a
+/* Arithmetic of the kernels.  Every call carries its own mode in cloudsc2_params.math_mode (1 fast, 2 precise); 0 there
+ * means the process default set here (initial value from the environment variable CLOUDSC2_MATH=fast|precise).  The
+ * default is only READ by the launchers, never changed by the library, so concurrent calls do not influence each other.
+ *   fast (default): quotients on shared / batch-inverted v_rcp_f64 reciprocals refined by one third-order step, a
  *     branch-free exp, tanh from one exp -- a few ulp from the correctly rounded values;
- *   1 precise: the reference's own operation order with IEEE division and libm exp/tanh/cosh.
- * cloudsc2_tl_taylor_run always evaluates in precise mode: its verdict is decided by round-off noise. */
+ *   precise: the reference's own operation order with IEEE division and libm exp/tanh/cosh.
+ * cloudsc2_tl_taylor_run evaluates in precise mode unless params.math_mode asks for fast explicitly: its verdict is
+ * decided by round-off noise (the fast-mode verdict is recorded by tests/test_gpu_parity.py). */
 void cloudsc2_set_math_mode(int precise);
 int cloudsc2_get_math_mode(void);
 

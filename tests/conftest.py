@@ -16,7 +16,12 @@ def _built() -> bool:
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # a fresh checkout has no built artefacts (they are git-ignored): build them once, as __graft_entry__.build() does
+    # (a failed build must not abort the session: every test that needs a missing artefact skips or fails by itself)
     if not _built() and os.path.exists("/opt/rocm/bin/hipcc"):
         import __graft_entry__
 
-        __graft_entry__.build()
+        try:
+            __graft_entry__.build()
+        except Exception as e:  # noqa: BLE001
+            print(f"conftest: __graft_entry__.build() failed ({e!r}); tests that need the missing artefacts will skip or fail",
+                  file=sys.stderr)

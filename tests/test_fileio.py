@@ -31,7 +31,7 @@ def test_input_file_round_trip(tmp_path):
     for k, v in tab.items():
         assert np.array_equal(np.asarray(v), np.asarray(got[k])), k
     for name, _ in B.Params._fields_:
-        if name in ("ceta", "reserved", "lregcl", "ldrain1d"):
+        if name in ("ceta", "math_mode", "lregcl", "ldrain1d"):
             continue
         assert getattr(p2, name) == getattr(prm, name), name
     assert np.array_equal(np.array(p2.ceta[:137]), c2.ceta_from_table(tab))  # dwarf_cloudsc.F90:100-102
