@@ -132,6 +132,10 @@ def _load() -> C.CDLL:
     lib.cloudsc2_tl_taylor_run.argtypes = [pp, C.c_int, C.c_int, C.c_int, C.c_double] + host18 + [dp, dp]
     lib.cloudsc2_ad_symmetry_run.argtypes = [pp, C.c_int, C.c_int, C.c_int, C.c_double] + host18 + [dp, dp]
     lib.cloudsc2_release_workspace.restype = None
+    lib.cloudsc2_device_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    lib.cloudsc2_device_free.argtypes = [C.c_void_p]
+    lib.cloudsc2_device_malloc_info.argtypes = [C.POINTER(C.c_int), dp, dp, dp]
+    lib.cloudsc2_device_malloc_info.restype = None
     lib.cloudsc2_taylor_verdict.argtypes = [dp, C.POINTER(C.c_int)]
     lib.cloudsc2_adjoint_verdict.argtypes = [C.c_double]
     expand_args = [rp, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_longlong, Field]
@@ -149,7 +153,7 @@ def _load() -> C.CDLL:
                  "cloudsc2_nl_launch", "cloudsc2_satur_launch", "cloudsc2_tl_launch", "cloudsc2_ad_launch",
                  "cloudsc2_taylor_sums_launch", "cloudsc2_adjoint_norms_launch", "cloudsc2_nl_run",
                  "cloudsc2_tl_taylor_run", "cloudsc2_ad_symmetry_run", "cloudsc2_taylor_verdict",
-                 "cloudsc2_adjoint_verdict"):
+                 "cloudsc2_adjoint_verdict", "cloudsc2_device_malloc", "cloudsc2_device_free"):
         getattr(lib, name).restype = C.c_int
     return lib
 
@@ -163,12 +167,104 @@ EXPORTED = ("cloudsc2_params_default", "cloudsc2_last_error", "cloudsc2_device_a
             "cloudsc2_adjoint_norms_launch", "cloudsc2_nl_run", "cloudsc2_tl_taylor_run", "cloudsc2_ad_symmetry_run",
             "cloudsc2_release_workspace", "cloudsc2_taylor_verdict", "cloudsc2_adjoint_verdict",
             "cloudsc2_expand_launch", "cloudsc2_validate_workspace_doubles", "cloudsc2_validate_launch",
-            "cloudsc2_expand_offsets", "cloudsc2_validate_relerr", "cloudsc2_validate_format", "cloudsc2_validate_header")
+            "cloudsc2_expand_offsets", "cloudsc2_validate_relerr", "cloudsc2_validate_format", "cloudsc2_validate_header",
+            "cloudsc2_device_malloc", "cloudsc2_device_free", "cloudsc2_device_malloc_info")
 
 
 def check(rc: int) -> None:
     if rc != 0:
         raise Cloudsc2Error(rc, (lib.cloudsc2_last_error() or b"").decode())
+
+
+class DeviceBuffer:
+    """Device memory from cloudsc2_device_malloc (placed: the fastest of several candidate allocations for the sweeps' write
+    stream, include/cloudsc2_hip.h).  Exposes __cuda_array_interface__ so that torch can view it; freed with the last
+    reference."""
+
+    def __init__(self, nbytes: int):
+        p = C.c_void_p()
+        check(lib.cloudsc2_device_malloc(C.byref(p), int(nbytes)))
+        self.ptr, self.nbytes = int(p.value or 0), int(nbytes)
+        self.__cuda_array_interface__ = {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 2}
+
+    def __del__(self):
+        if getattr(self, "ptr", 0):
+            lib.cloudsc2_device_free(C.c_void_p(self.ptr))
+            self.ptr = 0
+
+
+def device_malloc_info() -> dict:
+    """Placement report of the most recent cloudsc2_device_malloc of this process."""
+    c = C.c_int()
+    b, m, w = C.c_double(), C.c_double(), C.c_double()
+    lib.cloudsc2_device_malloc_info(C.byref(c), C.byref(b), C.byref(m), C.byref(w))
+    return {"candidates": c.value, "probe_ms_best": b.value, "probe_ms_median": m.value, "probe_ms_worst": w.value}
+
+
+# CLOUDSC2_STATE_ALLOC=torch: the Python mirror's device arrays come from torch's caching allocator (plain hipMalloc) instead
+# of cloudsc2_device_malloc -- A/B measurements of the placement effect only.
+STATE_ALLOC_TORCH = os.environ.get("CLOUDSC2_STATE_ALLOC", "library").strip().lower() == "torch"
+
+
+class DeviceArena:
+    """ONE placed allocation (cloudsc2_device_malloc) from which a set of arrays is carved, 256-byte aligned -- the Python
+    counterpart of the library's own Arena (csrc/cloudsc2_driver.inc).  One allocation per state means one placement scan
+    per state, and no array wastes the tail of a chunk."""
+
+    ALIGN = 256
+
+    def __init__(self, nbytes: int, device="cuda:0"):
+        import torch
+
+        self.device = torch.device(device)
+        self.nbytes = int(nbytes)
+        self.used = 0
+        if STATE_ALLOC_TORCH:
+            self.buf = None
+            self.raw = torch.empty(max(self.nbytes, 1), dtype=torch.uint8, device=self.device)
+        else:
+            with torch.cuda.device(self.device):
+                self.buf = DeviceBuffer(max(self.nbytes, 1))
+                self.raw = torch.as_tensor(self.buf, device=self.device)  # uint8 view; keeps `buf` alive
+            self.info = device_malloc_info()
+
+    @staticmethod
+    def size_of(shapes, itemsize: int) -> int:
+        total = 0
+        for shp in shapes:
+            n = itemsize
+            for d in shp:
+                n *= int(d)
+            total += (n + DeviceArena.ALIGN - 1) // DeviceArena.ALIGN * DeviceArena.ALIGN
+        return total
+
+    def take(self, shape, dtype=None, zero: bool = False):
+        import torch
+
+        dtype = torch_real() if dtype is None else dtype
+        itemsize = torch.empty((), dtype=dtype).element_size()
+        n = itemsize
+        for d in shape:
+            n *= int(d)
+        if self.used + n > self.nbytes:
+            raise MemoryError("DeviceArena exhausted")
+        t = self.raw[self.used: self.used + n].view(dtype).reshape(tuple(shape))
+        self.used += (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        t._cloudsc2_arena = self  # the view holds the owner
+        return t.zero_() if zero else t
+
+
+def device_empty(shape, dtype=None, device="cuda:0"):
+    """An uninitialised torch tensor of `shape` in memory from cloudsc2_device_malloc (torch only VIEWS the memory)."""
+    import torch
+
+    dtype = torch_real() if dtype is None else dtype
+    itemsize = torch.empty((), dtype=dtype).element_size()
+    return DeviceArena(DeviceArena.size_of([shape], itemsize), device).take(shape, dtype)
+
+
+def device_zeros(shape, dtype=None, device="cuda:0"):
+    return device_empty(shape, dtype, device).zero_()
 
 
 def default_params(ceta=None, *, lregcl: bool = False, levapls2: bool = False, ldrain1d: bool = False) -> Params:

@@ -19,6 +19,7 @@
 #include <cmath>
 #include <initializer_list>
 #include <mutex>
+#include <stddef.h>
 #include <string>
 #include <thread>
 #include <utility>
@@ -866,4 +867,5 @@ int cloudsc2_adjoint_verdict(double znormg) { return (znormg < 10000.0) ? 1 : 0;
 
 }  // extern "C"
 
+#include "cloudsc2_alloc.inc"
 #include "cloudsc2_driver.inc"

@@ -93,8 +93,9 @@ class FlatFields:
         self.kind = kind
         names = B.IN_NAMES if kind == "in" else B.OUT_NAMES
         half = {"paph"} if kind == "in" else {"fplsl", "fplsn", "fhpsl", "fhpsn"}
-        mk = torch.zeros if zero else torch.empty
-        self.t = {n: mk((nb, nlev + (1 if n in half else 0), nproma), dtype=B.torch_real(), device=device) for n in names}
+        shapes = {n: (nb, nlev + (1 if n in half else 0), nproma) for n in names}
+        arena = B.DeviceArena(B.DeviceArena.size_of(shapes.values(), B.REAL_BYTES), device)  # one placed allocation
+        self.t = {n: arena.take(shp, zero=zero) for n, shp in shapes.items()}
         self.nlev, self.nproma = nlev, nproma
 
     def block(self):
@@ -121,9 +122,15 @@ class DeviceState:
         self.device = torch.device(device)
         self.nproma, self.nlev, self.ngptot, self.ptsphy = st.nproma, st.nlev, st.ngptot, st.ptsphy
         self.nb = nblocks_of(st.ngptot, st.nproma)
-        for n in self.FULL + self.HALF + ("B_CML", "B_LOC", "PCLV"):
-            setattr(self, n, torch.from_numpy(getattr(st, n)).to(self.device))
-        self.QSAT = torch.zeros_like(self.PT)
+        names = self.FULL + self.HALF + ("B_CML", "B_LOC", "PCLV")
+        shapes = [getattr(st, n).shape for n in names] + [st.PT.shape]
+        self.arena = B.DeviceArena(B.DeviceArena.size_of(shapes, B.REAL_BYTES), self.device)  # one placed allocation
+        for n in names:
+            h = getattr(st, n)
+            d = self.arena.take(h.shape)
+            d.copy_(torch.from_numpy(h))
+            setattr(self, n, d)
+        self.QSAT = self.arena.take(st.PT.shape, zero=True)
         self._keep = []
 
     @classmethod
@@ -142,13 +149,16 @@ class DeviceState:
         self.nb = nblocks_of(ngptot, nproma)
         self._keep = []
         period = klon if period is None else period
-        z = lambda *shape: torch.zeros(shape, dtype=B.torch_real(), device=self.device)  # noqa: E731
+        full, half = (self.nb, nlev, nproma), (self.nb, nlev + 1, nproma)
+        shapes = [full] * (len(self.FULL) + 1) + [half] * len(self.HALF) + [(self.nb, 8, nlev, nproma)] * 2 + [(self.nb, 5, nlev, nproma)]
+        self.arena = B.DeviceArena(B.DeviceArena.size_of(shapes, B.REAL_BYTES), self.device)  # one placed allocation
+        z = lambda *shape: self.arena.take(shape, zero=True)  # noqa: E731
         for n in self.FULL:
-            setattr(self, n, z(self.nb, nlev, nproma))
+            setattr(self, n, z(*full))
         for n in self.HALF:
-            setattr(self, n, z(self.nb, nlev + 1, nproma))
+            setattr(self, n, z(*half))
         self.B_CML, self.B_LOC, self.PCLV = z(self.nb, 8, nlev, nproma), z(self.nb, 8, nlev, nproma), z(self.nb, 5, nlev, nproma)
-        self.QSAT = z(self.nb, nlev, nproma)
+        self.QSAT = z(*full)
         S, H = nproma * nlev, nproma * (nlev + 1)
         jobs = [(n, getattr(self, n), 0, S if tab[n].shape[0] == nlev else H)
                 for n in ("PT", "PQ", "PAP", "PAPH", "PLU", "PLUDE", "PMFU", "PMFD", "PA", "PSUPSAT")]
@@ -273,7 +283,7 @@ class DeviceState:
         return ff
 
     def new_scratch(self):
-        return self.torch.empty((self.nb, self.nlev, self.nproma), dtype=B.torch_real(), device=self.device)
+        return B.device_empty((self.nb, self.nlev, self.nproma), device=self.device)
 
     def download(self, st: Cloudsc2State) -> Cloudsc2State:
         for n in ("B_LOC", "PA", "PCOVPTOT", "PFPLSL", "PFPLSN", "PFHPSL", "PFHPSN"):

@@ -3,7 +3,10 @@
 Checker = the unmodified reference Fortran (oracle/_ref/libcloudsc2_ref.so) when it travelled to the box, otherwise
 the C restatement (oracle/libcloudsc2_oracle.so).  Tolerances: BASELINE.json's north_star asks for NL within 1e-10
 relative in fp64; the kernels run with FMA contraction and the device libm, the checker without FMA on the host
-libm, so agreement is expected at ~1e-13 and the tests assert 1e-10 (NL), 1e-9 (TL, AD: sums of many cancelling terms).
+libm, so agreement is expected at ~1e-13.  Any difference much larger than that is a flipped branch or a logic error,
+not rounding, so the tests assert 1e-12 for NL (measured <= 5e-14) and 1e-11 for TL and AD (sums of many
+cancelling terms; measured <= 4e-12 over the fuzz cases of tests/fuzz_parity.py) -- two orders tighter than the 1e-10
+BASELINE.json asks for.
 """
 from __future__ import annotations
 
@@ -15,8 +18,8 @@ from tests.util import B, c2, flat_fields, refcall, relerr, set_lib_params
 
 pytestmark = pytest.mark.gpu
 
-NL_TOL = 1e-10
-TLAD_TOL = 1e-9
+NL_TOL = 1e-12
+TLAD_TOL = 1e-11
 
 
 def checker():
@@ -341,6 +344,111 @@ def test_full_size_tl_ad_properties():
     for n, t in xa.t.items():
         c = columns(t)
         assert torch.equal(c.reshape(-1, 100, c.shape[1]), c[:100].expand(ngptot // 100, 100, c.shape[1])), n
+
+
+@pytest.mark.parametrize("nproma", [32, 128])
+def test_full_size_nl_matches_the_reference_directly(nproma):
+    """BASELINE configs[1] at its full size, compared DIRECTLY (every output, every column) with the checker's own driver:
+    160 000 columns x 137 levels, state tiled on the device (cloudsc2_expand_launch) vs. the same state tiled on the host
+    and run through CLOUDSC_DRIVER of the reference (cloudsc_driver_mod.F90:73-119, OpenMP over the blocks)."""
+    import torch
+
+    if not refcall.have_ref():
+        pytest.skip("needs oracle/_ref (the reference driver) on the box")
+    ngptot = 160000
+    tab = c2.synthetic_table()
+    prm = c2.default_params(c2.ceta_from_table(tab))
+    want = c2.state_from_table(tab, nproma, ngptot)
+    chk = refcall.RefLib()
+    set_lib_params(chk, prm)
+    chk.driver(0, 16, nproma, want.nlev, ngptot, want.ptsphy, want.driver_arrays())
+    ds = c2.DeviceState.from_table(tab, nproma, ngptot)
+    ds.nl(prm)
+    torch.cuda.synchronize()
+    got = ds.download(c2.state_from_table(tab, nproma, ngptot, poison_outputs=5.0))
+    worst = {}
+    for n, r in want.outputs().items():
+        g = got.outputs()[n]
+        assert np.all(np.isfinite(g)), n
+        worst[n] = relerr(r, g)
+        assert worst[n] <= NL_TOL, (n, worst[n])
+    print("full-size NL, NPROMA", nproma, "worst relative difference per field:", {k: f"{v:.1e}" for k, v in worst.items()})
+
+
+@pytest.mark.parametrize("flags", [dict(lregcl=True), dict()])
+def test_tl_ad_16384_columns_match_checker_directly(flags):
+    """BASELINE configs[3] size (NGPTOT = 16384): every TL output and every input adjoint of every column against the
+    checker's CLOUDSC2TL / CLOUDSC2AD, block by block -- not through the adjoint identity."""
+    nproma, ngptot = 128, 16384
+    tab = c2.synthetic_table()
+    r = _device_tl_ad(tab, nproma, ngptot, flags)
+    worst_tl = max(relerr(r["tl_ref"][n], r["tl_dev"][n]) for n in r["tl_ref"])
+    assert worst_tl <= TLAD_TOL, worst_tl
+    assert_outputs_close(r["traj_ref"], r["traj_dev"], NL_TOL)
+    worst_ad = 0.0
+    for n in r["x_ref"]:
+        ref_inc = r["x_ref"][n] - r["x0"][n] if n != "supsat" else r["x_ref"][n]
+        got_inc = r["x_dev"][n] - r["x0"][n] if n != "supsat" else r["x_dev"][n]
+        scale = max(np.abs(r["x_ref"][n]).max(), 1e-300)
+        worst_ad = max(worst_ad, np.abs(got_inc - ref_inc).max() / scale)
+    assert worst_ad <= TLAD_TOL, worst_ad
+    print(f"16384 columns {flags}: worst TL {worst_tl:.1e}, worst AD {worst_ad:.1e}")
+
+
+def test_taylor_test_in_fast_math():
+    """The Taylor test evaluated with the FAST-math kernels (the ones bench.py times), requested per call through
+    cloudsc2_params.math_mode = 1.  The verdict's V-shape rule (cloudsc_driver_tl_mod.F90:276-309) is decided by the
+    round-off of the finite differences, which in fast math is as small as the reference's but not monotone; what must hold
+    for a correct TL is the convergence itself: the ratio reaches 1 to better than 1e-5 and does so by lambda = 1e-4 at
+    the latest (ISTART <= 4, :279-283).  The ratios, ISTART and the penalty are printed (DESIGN.md 4 quotes them)."""
+    tab = c2.synthetic_table()
+    for nproma in (32, 1):
+        prm = c2.default_params(c2.ceta_from_table(tab), lregcl=False)
+        prm.math_mode = 1
+        zn, ok, itest, _ = c2.run_state(prm, c2.state_from_table(tab, nproma, 100), "tl")
+        prm.math_mode = 2
+        znp, okp, itestp, _ = c2.run_state(prm, c2.state_from_table(tab, nproma, 100), "tl")
+        z = np.abs(1.0 - zn)
+        istart = int(np.argmax(z < 0.5)) + 1 if np.any(z < 0.5) else 0
+        print(f"NPROMA {nproma} fast   : ratios-1 {np.array2string(zn - 1.0, precision=2)} ISTART {istart} penalty {itest} passed {ok}")
+        print(f"NPROMA {nproma} precise: ratios-1 {np.array2string(znp - 1.0, precision=2)} penalty {itestp} passed {okp}")
+        assert np.all(np.isfinite(zn))
+        assert 1 <= istart <= 4, (nproma, zn)
+        assert z.min() < 1e-5, (nproma, zn)
+        assert np.allclose(zn[:6], znp[:6], rtol=1e-6, atol=0), (zn, znp)  # the two arithmetics agree where the test is not noise
+        assert okp
+
+
+def test_math_mode_is_per_call():
+    """cloudsc2_params.math_mode selects the arithmetic of ONE call; the process default is only read.  Fast and precise
+    results differ in the last bits, and a precise call in between must not change what a default-mode call returns."""
+    import torch
+
+    tab = c2.random_table(137, 100, seed=21)
+    ds = c2.DeviceState.from_table(tab, 64, 1000)
+
+    def run(mode):
+        prm = c2.default_params(c2.ceta_from_table(tab))
+        prm.math_mode = mode
+        ds.nl(prm)
+        torch.cuda.synchronize()
+        return ds.PFPLSN.clone(), ds.B_LOC.clone()
+
+    default_is_precise = B.get_math_mode()
+    f0 = run(1)
+    p = run(2)
+    f1 = run(1)
+    d = run(0)
+    assert B.get_math_mode() == default_is_precise          # nothing process-wide was changed by the calls
+    assert torch.equal(f0[0], f1[0]) and torch.equal(f0[1], f1[1])
+    assert not torch.equal(f0[0], p[0])                      # the two arithmetics differ in the last bits ...
+    assert relerr(p[0].cpu().numpy(), f0[0].cpu().numpy()) < 1e-12  # ... and only there
+    want = p if default_is_precise else f0
+    assert torch.equal(d[0], want[0]) and torch.equal(d[1], want[1])
+    prm = c2.default_params(c2.ceta_from_table(tab))
+    prm.math_mode = 3
+    with pytest.raises(c2.Cloudsc2Error):
+        ds.nl(prm)
 
 
 def test_offset_variants_give_the_same_bits(tmp_path):
