@@ -3,16 +3,16 @@
 
 One "step" = one pass of the NL kernel over this rank's NGPTOT=160000 columns x 137 levels (fp64), inputs resident
 in HBM.  Weak scaling: every rank owns its own 160000-column sub-range of the global columns (the reference's MPI
-split); there is no collective in the data path.  Prints ONE JSON line (rank 0).
+split); there is no collective in the data path.  Prints ONE JSON line (rank 0).  `--gpus N` without a launcher starts
+the N ranks itself; under `python -m torch.distributed.run` it uses the launcher's ranks.
 
-Before the measurement the state is placed: which physical HBM an allocation lands in decides up to 17 % of the kernel
-time on this part, so candidates are allocated in several regions of the 288 GB (--placement-regions),
-each is timed with ten launches, and the fastest is used for the W warm-up and K timed steps.  Every candidate's
-time is in config.placement; --placement-regions 0 takes whatever the first allocation gets.
+The state is the first and only allocation of the process and comes from the library's allocator, which places it
+(cloudsc2_device_malloc; profiles/r02_hbm_placement.md): bench.py does not search.  `roofline.unplaced_first_allocation`
+is the same measurement in a fresh process with the placement switched off.
 
-The line also carries `cpu_baseline` (the reference on the host cores, rank 0 at N=1) and, at N=1, `companion_kernels`:
-the same bench for TL and AD, each run as a child process after the NL measurement (BASELINE.json's metric names all
-three kernels); neither is inside the timed region.
+The line also carries `cpu_baseline` (the reference on the host cores, rank 0 at N=1) and, at N=1, from child processes run
+after the measurement: `companion_kernels` (the same bench for TL and AD -- BASELINE.json's metric names all three) and
+`target_config` (NL at 1 048 576 columns, north_star's target); none of them is inside the timed region.
 """
 from __future__ import annotations
 
@@ -153,6 +153,18 @@ def spawn_ranks(ngpus: int, argv) -> int:
     return 0
 
 
+def child_bench(extra_args, env=None, timeout=900):
+    """Run this script as a fresh child process (own device memory, own placement) and return its JSON line."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__)] + [str(a) for a in extra_args]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=None if env is None else {**os.environ, **env})
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise RuntimeError(f"child bench failed (rc {r.returncode}): {r.stderr[-400:]}")
+    return json.loads(lines[-1])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -162,13 +174,15 @@ def main():
     ap.add_argument("--nproma", type=int, default=128)
     ap.add_argument("--kernel", choices=["nl", "tl", "ad"], default="nl")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-companions", action="store_true", help="skip the short TL and AD timings appended to the NL line")
+    ap.add_argument("--no-companions", action="store_true",
+                    help="skip everything appended to the headline line from child processes: TL and AD timings, the 1 M-column "
+                         "NL target configuration, the unplaced first allocation")
     ap.add_argument("--precision", choices=["double", "single"], default=os.environ.get("CLOUDSC2_PRECISION", "double"),
                     help="single = the fp32 library (the reference's -DSINGLE build); the headline metric is double")
     ap.add_argument("--levapls2", action="store_true", help="switch the evaporation branch on (off in every shipped config)")
-    ap.add_argument("--placement-regions", default="0,9,18,27,36,45,54,63,72,81,90,99,108,117,126,135,144,153,162,171,180,189,198,207",
-                    help="GiB offsets in HBM at which candidate placements of the state are timed before the measurement "
-                         "(the fastest is used; '0' = just allocate)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="no GPU work: start the ranks, rendezvous, shard the columns, reduce fake verdict norms, print the line "
+                         "(CPU rehearsal of the launch path; tests/test_bench_launch.py)")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -189,6 +203,20 @@ def main():
     fp = "fp32" if single else "fp64"
     variant = ", the -DSINGLE variant" if single else ""
 
+    if args.rendezvous_only:
+        rank, local, world = c2dist.init_process_group("gloo")
+        col0, ncols = c2dist.shard(args.ngptot * world, rank, world)
+        tl = c2dist.allreduce_max([1.0 + 10.0 ** (-(k + 1)) * (rank + 1) for k in range(10)])
+        ad = c2dist.allreduce_max([5.0 + rank])
+        per_rank = c2dist.allgather_scalar(float(col0))
+        if rank == 0:
+            print(json.dumps({"metric": "rendezvous only (no GPU work)", "n_gpus": world, "rendezvous_only": True,
+                              "first_column_per_rank": per_rank, "columns_per_rank": ncols,
+                              "verdicts": {"tl_znormg": [float(x) for x in tl], "ad_znormg": float(ad[0])}}), flush=True)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
     rank, local, world = c2dist.init_process_group()
     if not torch.cuda.is_available() or not c2.device_available():
         raise SystemExit("bench.py needs a HIP device: the CLOUDSC2 engine has no CPU path")
@@ -200,61 +228,30 @@ def main():
     col0 = rank * args.ngptot  # weak scaling: rank r owns global columns [r*NGPTOT, (r+1)*NGPTOT)
     stream = torch.cuda.current_stream(dev)
 
-    def make_workload():
-        """The state (tiled on the device from the 100-column table, cloudsc2_expand_launch: no host copy exists) and
-        whatever else the kernel under test touches; returns (step, bytes per column, kernel name, keep-alive)."""
-        ds = c2.DeviceState.from_table(tab, args.nproma, args.ngptot, dev, start=col0)
-        nlev = ds.nlev
-        if args.kernel == "nl":
-            return (lambda: ds.nl(prm, stream)), c2.bytes_per_column(nlev, "nl_driver"), \
-                "nl_kernel<F> (SATUR + CLOUDSC2 fused; fast math, no evaporation branch, 32-bit offsets when buffers < 4 GiB)", ds
+    # The state: tiled on the device from the 100-column table (cloudsc2_expand_launch: no host copy exists) into ONE arena
+    # from the library's allocator, which places it (cloudsc2_device_malloc: the fastest of up to 12 candidate allocations
+    # for the sweeps' write stream, profiles/r02_hbm_placement.md).  This is the first and only state of the process: what
+    # any caller of the C ABI gets, no search here.
+    ds = c2.DeviceState.from_table(tab, args.nproma, args.ngptot, dev, start=col0)
+    placement = dict(getattr(ds.arena, "info", {}))
+    nlev = ds.nlev
+    if args.kernel == "nl":
+        step, bpc, keep = (lambda: ds.nl(prm, stream)), c2.bytes_per_column(nlev, "nl_driver"), ds
+        kname = "nl_kernel<F> (SATUR + CLOUDSC2 fused; fast math, no evaporation branch, 32-bit offsets when buffers < 4 GiB)"
+    else:
         ds.satur(prm, stream)
         inc = ds.increments(zero_supsat=(args.kernel == "ad"))
         dout = c2.FlatFields("out", ds.nb, ds.nlev, ds.nproma, dev)
         if args.kernel == "tl":
-            return (lambda: ds.tl(prm, inc, dout, stream)), c2.bytes_per_column(nlev, "tl"), \
-                "tl_kernel<C2F_QSAT> (CLOUDSC2TL, trajectory recomputed, not stored)", (ds, inc, dout)
-        ds.tl(prm, inc, dout, stream)
-        scratch = ds.new_scratch()
-        # + carry checkpoint plane (write + read)
-        return (lambda: ds.ad(prm, inc, dout, scratch, stream)), c2.bytes_per_column(nlev, "ad") + 2 * c2.binding.REAL_BYTES * nlev, \
-            "ad_kernel<C2F_QSAT> (CLOUDSC2AD: trajectory pass + reverse pass)", (ds, inc, dout, scratch)
-
-    # Where in the 288 GB of HBM the state lives decides up to 17 % of the kernel time (stable for the life of an allocation,
-    # different per box: DESIGN.md 5, tools/placement_probe.py).  As a long-running model would at start-up, candidates are
-    # placed in several regions of the memory (spacer allocations in between, never touched), each is timed, the fastest is
-    # used; everything stays allocated so the chosen placement is not disturbed.  All candidates' times are reported.
-    regions = [float(x) for x in args.placement_regions.split(",") if x.strip() != ""] or [0.0]
-    cands, trial_ms, spacers = [], [], []
-    for r_gib in regions:
-        used = torch.cuda.memory_reserved(dev) / 2**30
-        if r_gib > used + 1.0:
-            try:
-                spacers.append(torch.empty(int((r_gib - used) * 2**30), dtype=torch.uint8, device=dev))
-            except RuntimeError:
-                break  # not that much memory left: stop exploring
-        try:
-            w = make_workload()
-        except RuntimeError:  # out of device memory: keep the candidates there are
-            torch.cuda.empty_cache()
-            if not cands:
-                raise
-            break
-        cands.append(w)
-    for w in cands:  # timed once all candidates exist: a fresh allocation needs ~10 launches to reach its steady time
-        for _ in range(5):
-            w[0]()
-        torch.cuda.synchronize(dev)
-        tev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
-        for a, b in tev:
-            a.record(stream)
-            w[0]()
-            b.record(stream)
-        torch.cuda.synchronize(dev)
-        trial_ms.append(sorted(a.elapsed_time(b) for a, b in tev)[2])  # median of 5 launches
-    best = min(range(len(cands)), key=lambda i: trial_ms[i])
-    step, bpc, kname, keep = cands[best]
-    nlev = (keep[0] if isinstance(keep, tuple) else keep).nlev
+            step, bpc, keep = (lambda: ds.tl(prm, inc, dout, stream)), c2.bytes_per_column(nlev, "tl"), (ds, inc, dout)
+            kname = "tl_kernel<C2F_QSAT> (CLOUDSC2TL, trajectory recomputed, not stored)"
+        else:
+            ds.tl(prm, inc, dout, stream)
+            scratch = ds.new_scratch()
+            step = lambda: ds.ad(prm, inc, dout, scratch, stream)  # noqa: E731
+            bpc = c2.bytes_per_column(nlev, "ad") + 2 * c2.binding.REAL_BYTES * nlev  # + carry checkpoint plane (write + read)
+            keep = (ds, inc, dout, scratch)
+            kname = "ad_kernel<C2F_QSAT> (CLOUDSC2AD: trajectory pass + reverse pass)"
 
     def barrier():
         if torch.distributed.get_backend() == "nccl":
@@ -262,7 +259,9 @@ def main():
         else:
             torch.distributed.barrier()
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 0)):
+        step()
+    for _ in range(15):  # a fresh allocation needs ~10 launches to reach its steady time; not counted as warm-up steps W
         step()
     torch.cuda.synchronize(dev)
     if world > 1:
@@ -286,24 +285,29 @@ def main():
     value = total_cols / (elapsed / args.steps)
 
     k_avg = float(kms.mean())
+    k_per_rank = c2dist.allgather_scalar(k_avg, dev) if world > 1 else [k_avg]
     achieved = bpc * args.ngptot / (k_avg * 1e-3) / 1e9
-    # HBM traffic from the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, calibrated as the MI355X guide
-    # prescribes; tools/pmc_workload.py + tools/pmc_parse.py), scaled per column to this launch.  null if not measured.
-    traffic = None
-    pmc_files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("pmc_traffic.json")) \
-        if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+    # HBM traffic: NOT measured in this run.  It is the figure of the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
+    # separate runs, calibrated as the MI355X guide prescribes; tools/pmc_workload.py + tools/pmc_parse.py), scaled per column
+    # to this launch; `traffic_source` names the file, null if there is none for this precision.
+    traffic, traffic_source = None, None
+    pdir = os.path.join(ROOT, "profiles")
+    pmc_files = sorted(f for f in os.listdir(pdir) if f.endswith("pmc_traffic.json")) if os.path.isdir(pdir) else []
     pmc_files = [f for f in pmc_files if ("_sp_" in f) == single]  # counters are per precision
     if pmc_files:
         try:
-            pmcs = [json.load(open(os.path.join(ROOT, "profiles", f))) for f in pmc_files]
-            same = [p for p in pmcs if p.get("ngptot") == args.ngptot]  # prefer the pass taken at this launch size
-            pmc = (same or pmcs)[-1]
+            pmcs = [(f, json.load(open(os.path.join(pdir, f)))) for f in pmc_files]
+            same = [p for p in pmcs if p[1].get("ngptot") == args.ngptot]  # prefer the pass taken at this launch size
+            fname, pmc = (same or pmcs)[-1]
             traffic = pmc["kernels"][args.kernel]["traffic_bytes"] / pmc["ngptot"] * args.ngptot
+            traffic_source = f"profiles/{fname} (rocprofv3 --pmc passes of an earlier run, scaled per column; not measured in this run)"
         except (KeyError, ValueError, OSError):
-            traffic = None
+            traffic, traffic_source = None, None
     roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_column": bpc,
-                "algorithmic_bytes": bpc * args.ngptot, "kernel_ms_avg": k_avg, "kernel_ms_min": float(kms.min())}
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "bytes_per_column": bpc,
+                "algorithmic_bytes": bpc * args.ngptot, "kernel_ms_avg": k_avg, "kernel_ms_min": float(kms.min()),
+                "kernel_ms_avg_per_rank": [round(x, 5) for x in k_per_rank],
+                "allocation": "first and only state of the process, from cloudsc2_device_malloc (placed by the library)"}
 
     out = {
         "metric": f"CLOUDSC2 {args.kernel.upper()} columns/sec ({fp}, NLEV=137)", "value": value, "unit": "columns/s",
@@ -314,44 +318,68 @@ def main():
                    "ngptot_per_gpu": args.ngptot, "nlev": nlev, "nproma": args.nproma,
                    "parallelism": f"columns sharded over {world} GPU(s), no data-path collective",
                    "device": device_info(torch, dev),
-                   "placement": {"regions_gib": regions[:len(trial_ms)], "kernel_ms_per_candidate": [round(x, 4) for x in trial_ms],
-                                 "chosen": best}},
+                   "placement": placement},
         "roofline": roofline,
     }
-    if rank == 0 and world == 1 and args.kernel == "nl" and not args.no_companions:
-        # BASELINE.json's metric names NL/TL/AD: the same bench for the other two kernels, each in a child process with its
-        # own placement search, after this process has given its device memory back.  Outside the timed region, never
-        # part of `value`; `--no-companions` skips it.
-        import subprocess
-
-        del cands, step, keep, spacers, w
+    companions = rank == 0 and world == 1 and args.kernel == "nl" and not args.no_companions
+    if companions:
+        # Everything below comes from fresh child processes started after this process has given its device memory back; none of
+        # it is inside the timed region or part of `value`; `--no-companions` skips it.
+        del step, keep, ds
         torch.cuda.empty_cache()
+        common = ["--no-cpu-baseline", "--no-companions", "--nproma", args.nproma, "--precision", args.precision] + \
+            (["--levapls2"] if args.levapls2 else [])
+        # (1) BASELINE.json's metric names NL/TL/AD: the same bench for the other two kernels
         comp = {}
         for kind in ("tl", "ad"):
-            cmd = [sys.executable, os.path.abspath(__file__), "--kernel", kind, "--steps", "30", "--warmup", "5", "--no-cpu-baseline",
-                   "--ngptot", str(args.ngptot), "--nproma", str(args.nproma), "--precision", args.precision,
-                   "--placement-regions", args.placement_regions] + (["--levapls2"] if args.levapls2 else [])
             try:
-                r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-                d = json.loads(r.stdout.strip().splitlines()[-1])
+                d = child_bench(["--kernel", kind, "--steps", 30, "--warmup", 5, "--ngptot", args.ngptot] + common)
                 comp[kind] = {"value": d["value"], "unit": d["unit"], "kernel_ms_avg": d["roofline"]["kernel_ms_avg"],
                               "bytes_per_column": d["roofline"]["bytes_per_column"], "frac": d["roofline"]["frac"],
                               "traffic": d["roofline"]["traffic"], "kernel": d["roofline"]["kernel"],
-                              "placement_ms": d["config"]["placement"]["kernel_ms_per_candidate"]}
+                              "placement": d["config"]["placement"]}
             except Exception as e:  # noqa: BLE001  (never let the companions break the headline line)
                 comp[kind] = {"error": repr(e)}
         out["companion_kernels"] = comp
+        # (2) north_star's target: >= 70 % of the HBM peak on the NL kernel at NGPTOT >= 1 M columns on one GPU
+        try:
+            d = child_bench(["--kernel", "nl", "--steps", 50, "--warmup", 5, "--ngptot", 1048576] + common)
+            out["target_config"] = {"workload": d["config"]["workload"], "ngptot": 1048576, "steps": d["steps"], "value": d["value"],
+                                    "unit": d["unit"], "ms_per_step": d["ms_per_step"], "kernel_ms_avg": d["roofline"]["kernel_ms_avg"],
+                                    "frac": d["roofline"]["frac"], "achieved": d["roofline"]["achieved"],
+                                    "bytes_per_column": d["roofline"]["bytes_per_column"], "placement": d["config"]["placement"],
+                                    "target": "north_star: NL >= 0.70 of the 8 TB/s HBM3E peak at NGPTOT >= 1 M columns"}
+        except Exception as e:  # noqa: BLE001
+            out["target_config"] = {"error": repr(e)}
+        # (3) what a caller gets WITHOUT the library's placement: first hipMalloc of a fresh process (CLOUDSC2_PLACE=0)
+        try:
+            d = child_bench(["--kernel", "nl", "--steps", 50, "--warmup", 5, "--ngptot", args.ngptot] + common, env={"CLOUDSC2_PLACE": "0"})
+            out["roofline"]["unplaced_first_allocation"] = {"kernel_ms_avg": d["roofline"]["kernel_ms_avg"], "frac": d["roofline"]["frac"],
+                                                            "note": "fresh process, CLOUDSC2_PLACE=0: plain first hipMalloc"}
+        except Exception as e:  # noqa: BLE001
+            out["roofline"]["unplaced_first_allocation"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.kernel == "nl":
         cb = cpu_baseline(tab, prm, 32, args.ngptot)
         if cb:
             out["cpu_baseline"] = cb
     if world > 1:
-        # the only inter-GPU exchange of the path: max-reduce the self-test verdict norms over RCCL (outside the timing)
+        # The only inter-GPU exchange of the path: max-reduce the two self-tests' verdict norms (outside the timing).  Each rank
+        # runs the Taylor test and the adjoint test on its own 1024-column sub-range; ZNORMG(10) and ZNORMG are all-reduced
+        # (MAX) over RCCL -- cloudsc_driver_tl_mod.F90:125, cloudsc_driver_ad_mod.F90:107 carried across ranks.
         try:
+            del step, keep, ds
+            torch.cuda.empty_cache()
+            ceta = c2.ceta_from_table(tab)
             vt = c2.state_from_table(tab, 64, 1024, col0=rank * 1024)
-            zad, _, _ = c2.run_state(c2.default_params(c2.ceta_from_table(tab), lregcl=True), vt, "ad")
-            znorm = c2dist.allreduce_max([zad], dev)
-            out["verdicts"] = {"ad_symmetry_max_eps": float(znorm[0]), "ad_ok": bool(c2.adjoint_verdict(float(znorm[0])))}
+            ztl, _, _, _ = c2.run_state(c2.default_params(ceta, lregcl=False), vt, "tl")
+            vt = c2.state_from_table(tab, 64, 1024, col0=rank * 1024)
+            zad, _, _ = c2.run_state(c2.default_params(ceta, lregcl=True), vt, "ad")
+            ztl_g = c2dist.allreduce_max(ztl, dev)
+            zad_g = c2dist.allreduce_max([zad], dev)
+            tl_ok, itest = c2.binding.taylor_verdict(ztl_g)
+            out["verdicts"] = {"backend": torch.distributed.get_backend(),
+                               "tl_znormg": [float(x) for x in ztl_g], "tl_passed": bool(tl_ok), "tl_penalty": int(itest),
+                               "ad_symmetry_max_eps": float(zad_g[0]), "ad_ok": bool(c2.adjoint_verdict(float(zad_g[0])))}
         except Exception as e:  # noqa: BLE001
             out["verdicts"] = {"error": repr(e)}
     if rank == 0:

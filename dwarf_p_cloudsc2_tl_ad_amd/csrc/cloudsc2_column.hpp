@@ -283,6 +283,8 @@ enum : unsigned {
   C2F_PERT = 8u,     // NL only: inputs perturbed by lambda*0.01*x (Taylor test)
   C2F_CKPT = 16u,    // NL only: trajectory pass of the adjoint (carry checkpoints)
   C2F_TRAJ = 8u,     // TL only: trajectory outputs are stored
+  C2F_ASSIGN = 8u,   // AD only: the input adjoints are ASSIGNED (x = A^T y) instead of accumulated (x += A^T y): their old
+                     // values are neither read nor needed to be zero (the adjoint test zeroes them first, cloudsc_driver_ad_mod.F90:198-213)
   C2F_OFF32 = 32u,   // every buffer of the launch < 4 GiB: 32-bit byte offsets (LaneOff32)
 };
 
@@ -502,7 +504,7 @@ struct AdLevelLoads {
   RawLevel xo;    // old input adjoints (PSUPSAT is assigned, not accumulated: not read)
 };
 
-template <bool HAS_QSAT, class OT>
+template <bool HAS_QSAT, bool ASSIGN, class OT>
 C2_HD void ad_load_level(AdArgsP ap, const LaneOffT<OT>& o, const LaneOffT<OT>& oa, OT osc, int nproma, int nlev, int jk,
                          AdLevelLoads& L) {
   const bool last = (jk == nlev - 1);
@@ -544,6 +546,12 @@ C2_HD void ad_load_level(AdArgsP ap, const LaneOffT<OT>& o, const LaneOffT<OT>& 
   L.ya.fplsl = ldg(pa.fplsl, oa.half + d1);
   L.ya.fhpsn = ldg(pa.fhpsn, oa.half + d1);
   L.ya.fhpsl = ldg(pa.fhpsl, oa.half + d1);
+  if (ASSIGN) {
+    // assign form: the old input adjoints are not read (16 planes of traffic less per level)
+    L.xo.pap = L.xo.q = L.xo.qsat = L.xo.t = L.xo.l = L.xo.i = L.xo.lude = L.xo.mfu = L.xo.mfd = RC(0.0);
+    L.xo.gt = L.xo.gq = L.xo.gl = L.xo.gi = L.xo.lu_k1 = L.xo.paph_k1 = RC(0.0);
+    return;
+  }
   const InPtrsRW px = ap->ain;
   L.xo.pap = ldg(px.pap, oa.full + d);
   L.xo.q = ldg(px.q, oa.full + d);
@@ -566,7 +574,7 @@ C2_HD void ad_load_level(AdArgsP ap, const LaneOffT<OT>& o, const LaneOffT<OT>& 
 template <unsigned F>
 C2_HD void ad_reverse_column(long long gcol, AdArgsP a) {
   constexpr bool HAS_QSAT = (F & C2F_QSAT) != 0, P = (F & C2F_PRECISE) != 0, EVAP = (F & C2F_EVAP) != 0;
-  constexpr bool OFF32 = (F & C2F_OFF32) != 0;
+  constexpr bool OFF32 = (F & C2F_OFF32) != 0, ASSIGN = (F & C2F_ASSIGN) != 0;
   typedef typename std::conditional<OFF32, unsigned, long long>::type OT;
   LaneOff o, oa64; bool active;
   if (!lane_setup(&a->nl.g, &a->nl.s, gcol, o, active)) return;
@@ -600,7 +608,7 @@ C2_HD void ad_reverse_column(long long gcol, AdArgsP a) {
     const OT d1 = d + row_off(OT(), nproma);
     AdArgsP ap = a;
     C2_LAUNDER(ap);
-    ad_load_level<HAS_QSAT>(ap, ol, oa, osc, nproma, nlev, jk, L);
+    ad_load_level<HAS_QSAT, ASSIGN>(ap, ol, oa, osc, nproma, nlev, jk, L);
     RawLevel& cur = L.cur;
     cur.paph_k1 = paph_k1;
     const RawLevel& xo = L.xo;
@@ -663,8 +671,14 @@ C2_HD void ad_reverse_column(long long gcol, AdArgsP a) {
   }
   InPtrsRWP ain = &a->ain;
   OutPtrsP aout = &a->aout;
-  ain->paph[oa64.half] += paph_pending;
-  ain->paph[oa64.half + (long long)nlev * nproma] += surf_acc;
+  if (ASSIGN) {
+    ain->paph[oa64.half] = paph_pending;
+    ain->paph[oa64.half + (long long)nlev * nproma] = surf_acc;
+    ain->lu[oa64.full] = RC(0.0);  // PLU(1) has no adjoint contribution (only PLU(JK+1) is read, cloudsc2.F90:435)
+  } else {
+    ain->paph[oa64.half] += paph_pending;
+    ain->paph[oa64.half + (long long)nlev * nproma] += surf_acc;
+  }
   // the adjoint of the (constant zero) top fluxes is discarded (cloudsc2ad.F90:1678-1679,917-919)
   aout->fplsl[oa64.half] = RC(0.0);
   aout->fplsn[oa64.half] = RC(0.0);

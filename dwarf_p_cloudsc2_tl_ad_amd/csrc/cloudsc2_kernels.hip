@@ -204,7 +204,7 @@ __global__ void C2_BOUNDS(C2_AD_WAVES) ad_reverse_kernel(AdArgs args) {
 }
 template <unsigned F>
 __global__ void C2_BOUNDS(C2_AD_WAVES) ad_kernel(AdArgs args) {
-  C2_KERNEL_BODY((nl_column<F | C2F_CKPT>(global_column(), &kernarg<AdArgs>()->nl)));
+  C2_KERNEL_BODY((nl_column<(F & ~C2F_ASSIGN) | C2F_CKPT>(global_column(), &kernarg<AdArgs>()->nl)));
   C2_KERNEL_BODY((ad_reverse_column<F>(global_column(), kernarg<AdArgs>())));
 }
 
@@ -219,8 +219,8 @@ template <class Args> using KernelFn = void (*)(Args);
   [[maybe_unused]] const std::array<KernelFn<Args>, NF> table = table##_make(std::make_integer_sequence<unsigned, NF>{});
 C2_VARIANT_TABLE(g_nl_kernels, nl_kernel, NlArgs, 64, !((F & C2F_PERT) && (F & C2F_CKPT)) && (C2_AD_FUSED == 1 ? !(F & C2F_CKPT) : true))
 C2_VARIANT_TABLE(g_tl_kernels, tl_kernel, TlArgs, 64, !(F & 16u))
-C2_VARIANT_TABLE(g_ad_reverse_kernels, ad_reverse_kernel, AdArgs, 64, C2_AD_FUSED != 1 && !(F & 24u))
-C2_VARIANT_TABLE(g_ad_kernels, ad_kernel, AdArgs, 64, C2_AD_FUSED != 0 && !(F & 24u))
+C2_VARIANT_TABLE(g_ad_reverse_kernels, ad_reverse_kernel, AdArgs, 64, C2_AD_FUSED != 1 && !(F & 16u))
+C2_VARIANT_TABLE(g_ad_kernels, ad_kernel, AdArgs, 64, C2_AD_FUSED != 0 && !(F & 16u))
 
 // ---------------------------------------------------------------------------------------------------------
 // Data-format kernels either side of the path: the input file holds KLON (=100) columns,
@@ -629,10 +629,10 @@ int cloudsc2_tl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
   return launch_variant(g_tl_kernels[f], args, g.ncols_pad, (hipStream_t)stream);
 }
 
-int cloudsc2_ad_launch(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
-                       const cloudsc2_inputs* traj_in, const cloudsc2_outputs* traj_out,
-                       const cloudsc2_inputs* adj_in, const cloudsc2_outputs* adj_out, cloudsc2_real* scratch,
-                       void* stream) {
+static int ad_launch_impl(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
+                          const cloudsc2_inputs* traj_in, const cloudsc2_outputs* traj_out,
+                          const cloudsc2_inputs* adj_in, const cloudsc2_outputs* adj_out, cloudsc2_real* scratch,
+                          void* stream, bool assign) {
   Geom g;
   int rc = check_geom(prm, nproma, nlev, ngptot, g);
   if (rc) return rc;
@@ -659,13 +659,28 @@ int cloudsc2_ad_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
   if (traj_in->qsat.ptr) f |= C2F_QSAT;
   if (precise_of(prm)) f |= C2F_PRECISE;
   if (args.nl.c.evap) f |= C2F_EVAP;
+  if (assign) f |= C2F_ASSIGN;
   if (fits_off32(g, nproma, nlev, {s.full, s.half, s.cml, s.clv, s.loc, sa.full, sa.half, sa.cml, sa.clv, sa.loc,
                                   (long long)nproma * nlev /* scratch */})) f |= C2F_OFF32;
   const bool fused = C2_AD_FUSED == 1 || (C2_AD_FUSED == 2 && g.ncols_pad > kAdSplitBelow);
   if (fused) return launch_variant(g_ad_kernels[f], args, g.ncols_pad, (hipStream_t)stream);
   // trajectory pass (NL kernel + carry checkpoints), then the reverse pass, in stream order
-  if ((rc = launch_variant(g_nl_kernels[f | C2F_CKPT], args.nl, g.ncols_pad, (hipStream_t)stream))) return rc;
+  if ((rc = launch_variant(g_nl_kernels[(f & ~C2F_ASSIGN) | C2F_CKPT], args.nl, g.ncols_pad, (hipStream_t)stream))) return rc;
   return launch_variant(g_ad_reverse_kernels[f], args, g.ncols_pad, (hipStream_t)stream);
+}
+
+int cloudsc2_ad_launch(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
+                       const cloudsc2_inputs* traj_in, const cloudsc2_outputs* traj_out,
+                       const cloudsc2_inputs* adj_in, const cloudsc2_outputs* adj_out, cloudsc2_real* scratch,
+                       void* stream) {
+  return ad_launch_impl(prm, ptsphy, nproma, nlev, ngptot, traj_in, traj_out, adj_in, adj_out, scratch, stream, false);
+}
+
+int cloudsc2_ad_launch_assign(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
+                              const cloudsc2_inputs* traj_in, const cloudsc2_outputs* traj_out,
+                              const cloudsc2_inputs* adj_in, const cloudsc2_outputs* adj_out, cloudsc2_real* scratch,
+                              void* stream) {
+  return ad_launch_impl(prm, ptsphy, nproma, nlev, ngptot, traj_in, traj_out, adj_in, adj_out, scratch, stream, true);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -30,6 +30,9 @@ def init_process_group(backend: str | None = None):
             # CLOUDSC2_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
             backend = os.environ.get("CLOUDSC2_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
+            if torch.cuda.device_count() < world and int(os.environ.get("LOCAL_WORLD_SIZE", world)) > torch.cuda.device_count():
+                raise RuntimeError(f"{world} ranks need {world} GPUs, this node has {torch.cuda.device_count()} "
+                                   "(CLOUDSC2_DIST_BACKEND=gloo rehearses the multi-rank path on fewer GPUs)")
             torch.cuda.set_device(local)
         elif torch.cuda.is_available():
             local = local % max(torch.cuda.device_count(), 1)  # rehearsal: ranks share the GPUs that exist
@@ -58,6 +61,23 @@ def allreduce_max(values, device=None) -> np.ndarray:
     t = torch.from_numpy(v.copy()).to(device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return t.cpu().numpy()
+
+
+def allgather_scalar(value: float, device=None) -> list:
+    """One double from every rank, in rank order (per-rank kernel times of the bench line)."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [float(value)]
+    v = np.zeros(dist.get_world_size(), dtype=np.float64)
+    v[dist.get_rank()] = value
+    # slots of the other ranks are zero: MAX would drop negative values, so reduce |v| and sign separately via SUM
+    import torch
+
+    dev = torch.device("cpu") if dist.get_backend() != "nccl" else (device or torch.device("cuda", torch.cuda.current_device()))
+    t = torch.from_numpy(v).to(dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(x) for x in t.cpu().numpy()]
 
 
 def allreduce_validation(stats: dict, device=None) -> dict:

@@ -259,11 +259,13 @@ class DeviceState:
         B.check(B.lib.cloudsc2_tl_launch(C.byref(prm), self.ptsphy, self.nproma, self.nlev, self.ngptot, C.byref(i),
                                          C.byref(o), C.byref(di), C.byref(do), self._stream(stream)))
 
-    def ad(self, prm: B.Params, adj_in: FlatFields, adj_out: FlatFields, scratch, stream=None, fused_satur: bool = False):
+    def ad(self, prm: B.Params, adj_in: FlatFields, adj_out: FlatFields, scratch, stream=None, fused_satur: bool = False,
+           assign: bool = False):
+        """CLOUDSC2AD; assign=True: adj_in = A^T adj_out instead of adj_in += A^T adj_out (cloudsc2_ad_launch_assign)."""
         i = self.traj_inputs(not fused_satur)
         o = self.traj_outputs()
         ai, ao = adj_in.block(), adj_out.block()
-        B.check(B.lib.cloudsc2_ad_launch(C.byref(prm), self.ptsphy, self.nproma, self.nlev, self.ngptot, C.byref(i),
+        B.check((B.lib.cloudsc2_ad_launch_assign if assign else B.lib.cloudsc2_ad_launch)(C.byref(prm), self.ptsphy, self.nproma, self.nlev, self.ngptot, C.byref(i),
                                          C.byref(o), C.byref(ai), C.byref(ao), C.c_void_p(scratch.data_ptr()),
                                          self._stream(stream)))
 

@@ -151,6 +151,15 @@ int cloudsc2_ad_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
                        const cloudsc2_inputs* adj_in, const cloudsc2_outputs* adj_out,
                        cloudsc2_real* scratch, void* stream);
 
+/* The same with the input adjoints ASSIGNED instead of accumulated: adj_in = A^T adj_out, the old contents of adj_in are
+ * neither read nor required to be zero (16 planes of reads less per level).  This is what "zero the increments, then call
+ * CLOUDSC2AD" (cloudsc_driver_ad_mod.F90:198-237) amounts to; cloudsc2_ad_symmetry_run uses it.  Padded tail columns of the
+ * last block are not written. */
+int cloudsc2_ad_launch_assign(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
+                              const cloudsc2_inputs* traj_in, const cloudsc2_outputs* traj_out,
+                              const cloudsc2_inputs* adj_in, const cloudsc2_outputs* adj_out,
+                              cloudsc2_real* scratch, void* stream);
+
 /* Taylor-test statistics for one lambda (ERROR_NORM, cloudsc_driver_tl_mod.F90:21-31, calls :233-244):
  * for each NPROMA block and each of the 10 output fields, sums over the block's active columns and all
  * levels of (F(x)-F(x+lambda dx)) and of (TL dx * lambda).  sums(NBLOCKS,10,2) device doubles. */

@@ -33,8 +33,8 @@ template <unsigned F> struct HcTl {
 };
 template <unsigned F> struct HcAd {
   static void run(long long gc, const AdArgs* a) {
-    if constexpr ((F & ~(C2F_QSAT | C2F_PRECISE | C2F_EVAP | C2F_OFF32)) == 0) {
-      nl_column<F | C2F_CKPT>(gc, &a->nl);
+    if constexpr ((F & ~(C2F_QSAT | C2F_PRECISE | C2F_EVAP | C2F_OFF32 | C2F_ASSIGN)) == 0) {
+      nl_column<(F & ~C2F_ASSIGN) | C2F_CKPT>(gc, &a->nl);
       ad_reverse_column<F>(gc, a);
     }
   }
@@ -78,10 +78,12 @@ static Geom hc_geom(int nproma, int nlev, int ngptot) {
 
 static int g_hc_precise = 0;
 static int g_hc_off32 = 0;
+static int g_hc_assign = 0;
 
 extern "C" {
 
 void hostcheck_set_precise(int p) { g_hc_precise = p; }
+void hostcheck_set_assign(int v) { g_hc_assign = v; }  // AD: assign the input adjoints instead of accumulating (C2F_ASSIGN)
 void hostcheck_set_off32(int v) { g_hc_off32 = v; }  // 32-bit byte offsets (C2F_OFF32) in all three sweeps
 
 int hostcheck_satur(const cloudsc2_params* prm, int nproma, int nlev, int ngptot, cloudsc2_field pap, cloudsc2_field t,
@@ -142,7 +144,7 @@ int hostcheck_ad(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev
   a.ain.gi = ain->gteni.ptr; a.ain.supsat = ain->supsat.ptr;
   a.nl.zero_plane = nullptr; a.nl.zero_stride = 0; a.nl.lam = 0.0; a.nl.ckpt = scratch;
   unsigned f = (in->qsat.ptr ? C2F_QSAT : 0u) | (g_hc_precise ? C2F_PRECISE : 0u) | (a.nl.c.evap ? C2F_EVAP : 0u) |
-               (g_hc_off32 ? C2F_OFF32 : 0u);
+               (g_hc_off32 ? C2F_OFF32 : 0u) | (g_hc_assign ? C2F_ASSIGN : 0u);
   for (long long gc = 0; gc < a.nl.g.ncols_pad; ++gc) hc_dispatch<HcAd, 64>(f, gc, &a);
   return 0;
 }

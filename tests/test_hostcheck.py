@@ -132,6 +132,27 @@ def test_tl_ad_columns(oracle, flags, nlev):
     for n in x:
         assert np.array_equal(x[n], x3[n]), ("off32 ad", n)
 
+    # the assign form of the adjoint (C2F_ASSIGN, cloudsc2_ad_launch_assign): x = A^T y into arrays full of garbage must equal
+    # the accumulate form into zeroed arrays bit for bit on the active columns, and must not touch the padded tail
+    hc.hostcheck_set_assign(1)
+    try:
+        got4 = st.copy()
+        i4, o4 = host_traj_blocks(got4, qsat)
+        x4 = {n: np.full_like(a, 7.25) for n, a in x.items()}
+        y4 = {n: a.copy() for n, a in tl.items()}
+        ai4, ao4 = flat_block("in", x4), flat_block("out", y4)
+        assert hc.hostcheck_ad(C.byref(prm), st.ptsphy, nproma, nlev, ngptot, C.byref(i4), C.byref(o4), C.byref(ai4), C.byref(ao4),
+                               scratch.ctypes.data) == 0
+    finally:
+        hc.hostcheck_set_assign(0)
+    for ibl in range(nb):
+        icend = min(nproma, ngptot - ibl * nproma)
+        for n in x:
+            assert np.array_equal(x[n][ibl][:, :icend], x4[n][ibl][:, :icend]), ("assign", n)
+            assert np.all(x4[n][ibl][:, icend:] == 7.25), ("assign touched the tail", n)
+        for n in y4:
+            assert np.all(y4[n][ibl][:, :icend] == 0.0), ("assign: output adjoint not consumed", n)
+
     ld = bool(flags.get("ldrain1d", False))
     for ibl in range(nb):
         icend = min(nproma, ngptot - ibl * nproma)
