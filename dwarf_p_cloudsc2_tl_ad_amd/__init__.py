@@ -10,4 +10,5 @@ from .binding import (Cloudsc2Error, Params, adjoint_verdict, default_params, de
                       set_math_mode, taylor_verdict)
 from .state import (Cloudsc2State, bytes_per_column, ceta_from_table, column_range, nblocks_of, random_table,  # noqa: F401
                     state_from_table, synthetic_table, validate_l1)
-from .driver import DeviceState, FlatFields, cloudsc_driver, cloudsc_driver_ad, cloudsc_driver_tl, run_state  # noqa: F401
+from .driver import (DeviceState, FlatFields, ResidentState, cloudsc_driver, cloudsc_driver_ad, cloudsc_driver_tl,  # noqa: F401
+                     run_state)

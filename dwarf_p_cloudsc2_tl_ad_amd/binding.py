@@ -134,6 +134,21 @@ def _load() -> C.CDLL:
     lib.cloudsc2_tl_taylor_run.argtypes = [pp, C.c_int, C.c_int, C.c_int, C.c_double] + host18 + [dp, dp]
     lib.cloudsc2_ad_symmetry_run.argtypes = [pp, C.c_int, C.c_int, C.c_int, C.c_double] + host18 + [dp, dp]
     lib.cloudsc2_release_workspace.restype = None
+    lib.cloudsc2_state_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    lib.cloudsc2_state_destroy.argtypes = [C.c_void_p]
+    lib.cloudsc2_state_destroy.restype = None
+    lib.cloudsc2_state_field.argtypes = [C.c_void_p, C.c_int, C.POINTER(Field)]
+    lib.cloudsc2_state_expand.argtypes = [C.c_void_p, C.c_int, rp, C.c_int, C.c_int, C.c_longlong]
+    lib.cloudsc2_state_upload.argtypes = [C.c_void_p] + host18
+    lib.cloudsc2_state_download.argtypes = [C.c_void_p] + [rp] * 7
+    lib.cloudsc2_state_nl.argtypes = [C.c_void_p, pp, C.c_double, C.c_int, dp]
+    lib.cloudsc2_state_tl_taylor.argtypes = [C.c_void_p, pp, C.c_double, dp, dp]
+    lib.cloudsc2_state_ad_symmetry.argtypes = [C.c_void_p, pp, C.c_double, dp, dp]
+    lib.cloudsc2_state_validate.argtypes = [C.c_void_p, C.c_int, C.c_int, rp, C.c_int, C.c_int, C.c_longlong, dp]
+    for name in ("cloudsc2_state_create", "cloudsc2_state_field", "cloudsc2_state_expand", "cloudsc2_state_upload",
+                 "cloudsc2_state_download", "cloudsc2_state_nl", "cloudsc2_state_tl_taylor", "cloudsc2_state_ad_symmetry",
+                 "cloudsc2_state_validate"):
+        getattr(lib, name).restype = C.c_int
     lib.cloudsc2_device_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
     lib.cloudsc2_device_free.argtypes = [C.c_void_p]
     lib.cloudsc2_device_malloc_info.argtypes = [C.POINTER(C.c_int), dp, dp, dp]
@@ -171,7 +186,15 @@ EXPORTED = ("cloudsc2_params_default", "cloudsc2_last_error", "cloudsc2_device_a
             "cloudsc2_release_workspace", "cloudsc2_taylor_verdict", "cloudsc2_adjoint_verdict",
             "cloudsc2_expand_launch", "cloudsc2_validate_workspace_doubles", "cloudsc2_validate_launch",
             "cloudsc2_expand_offsets", "cloudsc2_validate_relerr", "cloudsc2_validate_format", "cloudsc2_validate_header",
-            "cloudsc2_device_malloc", "cloudsc2_device_free", "cloudsc2_device_malloc_info")
+            "cloudsc2_device_malloc", "cloudsc2_device_free", "cloudsc2_device_malloc_info",
+            "cloudsc2_state_create", "cloudsc2_state_destroy", "cloudsc2_state_field", "cloudsc2_state_expand",
+            "cloudsc2_state_upload", "cloudsc2_state_download", "cloudsc2_state_nl", "cloudsc2_state_tl_taylor",
+            "cloudsc2_state_ad_symmetry", "cloudsc2_state_validate")
+
+# field ids of the resident-state API (enum in include/cloudsc2_hip.h)
+F_FULL = {"PT": 0, "PQ": 1, "PAP": 2, "PAPH": 3, "PLU": 4, "PLUDE": 5, "PMFU": 6, "PMFD": 7, "PA": 8, "PSUPSAT": 9, "PCOVPTOT": 10,
+          "PFPLSL": 11, "PFPLSN": 12, "PFHPSL": 13, "PFHPSN": 14, "QSAT": 15}
+F_CML_T, F_LOC_T, F_PCLV_QL = 16, 24, 32
 
 
 def check(rc: int) -> None:

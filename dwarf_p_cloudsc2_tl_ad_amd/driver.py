@@ -291,3 +291,65 @@ class DeviceState:
         for n in ("B_LOC", "PA", "PCOVPTOT", "PFPLSL", "PFPLSN", "PFHPSL", "PFHPSN"):
             getattr(st, n)[...] = getattr(self, n).cpu().numpy()
         return st
+
+
+class ResidentState:
+    """The library-owned resident GLOBAL_STATE (cloudsc2_state_* of include/cloudsc2_hip.h): what the Fortran mains use with
+    CLOUDSC2_RESIDENT=1.  No torch: tables go in as numpy arrays, statistics and verdict norms come back as numbers."""
+
+    TABLE_FIELDS = {"PT": 0, "PQ": 1, "PAP": 2, "PAPH": 3, "PLU": 4, "PLUDE": 5, "PMFU": 6, "PMFD": 7, "PA": 8, "PSUPSAT": 9,
+                    "TENDENCY_CML_T": B.F_CML_T + PLANE_T, "TENDENCY_CML_Q": B.F_CML_T + PLANE_Q,
+                    "TENDENCY_CML_QL": B.F_CML_T + PLANE_QL, "TENDENCY_CML_QI": B.F_CML_T + PLANE_QI,
+                    "PCLV_QL": B.F_PCLV_QL, "PCLV_QI": B.F_PCLV_QL + 1}
+
+    def __init__(self, nproma: int, nlev: int, ngptot: int):
+        self.h = C.c_void_p()
+        B.check(B.lib.cloudsc2_state_create(int(nproma), int(nlev), int(ngptot), C.byref(self.h)))
+        self.nproma, self.nlev, self.ngptot = nproma, nlev, ngptot
+
+    def __del__(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            B.lib.cloudsc2_state_destroy(self.h)
+            self.h = C.c_void_p()
+
+    @classmethod
+    def from_table(cls, tab: dict, nproma: int, ngptot: int, start: int = 0, period: int | None = None) -> "ResidentState":
+        nlev, klon = tab["PT"].shape
+        self = cls(nproma, nlev, ngptot)
+        self.ptsphy = float(tab["PTSPHY"])
+        for name, fid in cls.TABLE_FIELDS.items():
+            t = np.ascontiguousarray(tab[name], dtype=B.REAL)
+            B.check(B.lib.cloudsc2_state_expand(self.h, fid, _ptr(t), klon, klon if period is None else period, start))
+        return self
+
+    def nl(self, prm: B.Params, repeats: int = 1) -> float:
+        ms = C.c_double()
+        B.check(B.lib.cloudsc2_state_nl(self.h, C.byref(prm), self.ptsphy, int(repeats), C.byref(ms)))
+        return ms.value
+
+    def tl_taylor(self, prm: B.Params):
+        zn, ms = (C.c_double * 10)(), C.c_double()
+        B.check(B.lib.cloudsc2_state_tl_taylor(self.h, C.byref(prm), self.ptsphy, zn, C.byref(ms)))
+        z = np.array(zn[:])
+        ok, itest = B.taylor_verdict(z)
+        return z, ok, itest, ms.value
+
+    def ad_symmetry(self, prm: B.Params):
+        zn, ms = C.c_double(), C.c_double()
+        B.check(B.lib.cloudsc2_state_ad_symmetry(self.h, C.byref(prm), self.ptsphy, C.byref(zn), C.byref(ms)))
+        return zn.value, B.adjoint_verdict(zn.value), ms.value
+
+    def validate(self, field: int, ref_table: np.ndarray, ndim: int = 1, start: int = 0, period: int | None = None) -> np.ndarray:
+        t = np.ascontiguousarray(ref_table, dtype=B.REAL)
+        klon = t.shape[-1]
+        st = (C.c_double * 5)()
+        B.check(B.lib.cloudsc2_state_validate(self.h, int(field), int(ndim), _ptr(t), klon, klon if period is None else period, start, st))
+        return np.array(st[:])
+
+    def download(self, st: Cloudsc2State) -> Cloudsc2State:
+        B.check(B.lib.cloudsc2_state_download(self.h, _ptr(st.B_LOC), _ptr(st.PA), _ptr(st.PCOVPTOT), _ptr(st.PFPLSL), _ptr(st.PFPLSN),
+                                              _ptr(st.PFHPSL), _ptr(st.PFHPSN)))
+        return st
+
+    def upload(self, st: Cloudsc2State):
+        B.check(B.lib.cloudsc2_state_upload(self.h, *[_ptr(a) for a in st.driver_arrays()]))

@@ -216,6 +216,51 @@ int cloudsc2_ad_symmetry_run(const cloudsc2_params* prm, int nproma, int nlev, i
 
 void cloudsc2_release_workspace(void);
 
+/* ------------------------------------------------------------------------------------------------
+ * Resident state: a GLOBAL_STATE (cloudsc2_array_state_mod.F90:26-79) that lives on the device and is owned by the
+ * library -- for callers whose model keeps its physics state in HBM, and for the Fortran mains' CLOUDSC2_RESIDENT=1 mode.
+ * The host-pointer entry points above spend 98 % of their time on PCIe; with a handle the flow of the reference main
+ * (LOAD -> driver -> VALIDATE) never builds the NPROMA-blocked arrays on the host:
+ *   cloudsc2_state_create     allocates all arrays as ONE placed allocation (cloudsc2_device_malloc), zero-filled
+ *                             (FIELD_INIT, :186-190); the layout is the reference's (include file header).
+ *   cloudsc2_state_expand     EXPAND_R2 (expand_mod.F90:270-302) of one field from a KLON-column HOST table (KLON, NLEVx),
+ *                             `period`/`start` as cloudsc2_expand_offsets gives them; repeated calls fill the state.
+ *   cloudsc2_state_upload / _download   the same transfers as the host-pointer drivers (what the kernels read / write).
+ *   cloudsc2_state_nl         SATUR + CLOUDSC2 over all blocks, `repeats` times back to back; *kernel_ms = mean device time.
+ *   cloudsc2_state_tl_taylor, cloudsc2_state_ad_symmetry   the two self-tests of cloudsc2_tl_taylor_run / _ad_symmetry_run
+ *                             on the resident state (their scratch arrays are a second allocation owned by the handle).
+ *   cloudsc2_state_validate   VALIDATE_R2/R3 (validate_mod.F90:165-261) of one field against a KLON-column HOST reference
+ *                             table (KLON, NLEVx, ndim): stats[5] as cloudsc2_validate_launch.
+ *   cloudsc2_state_field      the device pointer + block stride of one field, for the kernel-level entry points.
+ * A handle belongs to the HIP device that was current when it was created; calls are synchronous.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct cloudsc2_state cloudsc2_state;
+enum {
+  CLOUDSC2_F_PT = 0, CLOUDSC2_F_PQ, CLOUDSC2_F_PAP, CLOUDSC2_F_PAPH, CLOUDSC2_F_PLU, CLOUDSC2_F_PLUDE, CLOUDSC2_F_PMFU,
+  CLOUDSC2_F_PMFD, CLOUDSC2_F_PA, CLOUDSC2_F_PSUPSAT, CLOUDSC2_F_PCOVPTOT,                  /* 0..10  */
+  CLOUDSC2_F_PFPLSL, CLOUDSC2_F_PFPLSN, CLOUDSC2_F_PFHPSL, CLOUDSC2_F_PFHPSN, CLOUDSC2_F_QSAT, /* 11..15 */
+  CLOUDSC2_F_CML_T = 16, /* + plane: T A Q QL QI QR QS QV = 16..23 (TENDENCY_CML) */
+  CLOUDSC2_F_LOC_T = 24, /* 24..31 (TENDENCY_LOC) */
+  CLOUDSC2_F_PCLV_QL = 32 /* 32..36 (PCLV: QL QI QR QS QV) */
+};
+int cloudsc2_state_create(int nproma, int nlev, int ngptot, cloudsc2_state** state);
+void cloudsc2_state_destroy(cloudsc2_state* state);
+int cloudsc2_state_field(const cloudsc2_state* state, int field, cloudsc2_field* f);
+int cloudsc2_state_expand(cloudsc2_state* state, int field, const cloudsc2_real* table, int klon, int period, long long start);
+int cloudsc2_state_upload(cloudsc2_state* state,
+                          const cloudsc2_real* pt, const cloudsc2_real* pq, const cloudsc2_real* b_cml, cloudsc2_real* b_loc,
+                          const cloudsc2_real* pap, const cloudsc2_real* paph, const cloudsc2_real* plu, const cloudsc2_real* plude,
+                          const cloudsc2_real* pmfu, const cloudsc2_real* pmfd, cloudsc2_real* pa, const cloudsc2_real* pclv,
+                          const cloudsc2_real* psupsat, cloudsc2_real* pcovptot, cloudsc2_real* pfplsl, cloudsc2_real* pfplsn,
+                          cloudsc2_real* pfhpsl, cloudsc2_real* pfhpsn);
+int cloudsc2_state_download(cloudsc2_state* state, cloudsc2_real* b_loc, cloudsc2_real* pa, cloudsc2_real* pcovptot,
+                            cloudsc2_real* pfplsl, cloudsc2_real* pfplsn, cloudsc2_real* pfhpsl, cloudsc2_real* pfhpsn);
+int cloudsc2_state_nl(cloudsc2_state* state, const cloudsc2_params* prm, double ptsphy, int repeats, double* kernel_ms);
+int cloudsc2_state_tl_taylor(cloudsc2_state* state, const cloudsc2_params* prm, double ptsphy, double znormg[10], double* kernel_ms);
+int cloudsc2_state_ad_symmetry(cloudsc2_state* state, const cloudsc2_params* prm, double ptsphy, double* znormg, double* kernel_ms);
+int cloudsc2_state_validate(cloudsc2_state* state, int field, int ndim, const cloudsc2_real* ref_table, int klon, int period,
+                            long long start, double stats[5]);
+
 /* Verdict logic of the two self-tests, pure host code (no device needed).
  * cloudsc2_taylor_verdict: cloudsc_driver_tl_mod.F90:272-311; znormg = raw ratios; returns 1 = PASSED;
  *   *itest = penalty / error code (13 when no lambda <= 1e-4 reaches |1-ratio| < 0.5).

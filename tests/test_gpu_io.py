@@ -236,3 +236,46 @@ def test_cpp_host_example_prints_the_same_report(tmp_path):
     ds.nl(prm2)
     _, text = ds.validate(ref)
     assert r.stdout.rstrip("\n") == text
+
+
+def test_resident_state_handle_equals_the_host_pointer_drivers():
+    """cloudsc2_state_* (the library-owned resident GLOBAL_STATE the Fortran mains use with CLOUDSC2_RESIDENT=1): expand from
+    the KLON-column tables, NL, download == the host-pointer driver on the host-tiled state, bit for bit; the two self-tests
+    return the same norms as cloudsc2_tl_taylor_run / cloudsc2_ad_symmetry_run; validation against the state's own outputs
+    gives zero error; upload of a host state gives the same results as expand."""
+    tab = c2.synthetic_table()
+    nproma, ngptot = 96, 1000
+    prm = c2.default_params(c2.ceta_from_table(tab))
+    want = c2.state_from_table(tab, nproma, ngptot, poison_outputs=3.0)
+    c2.run_state(prm, want, "nl")
+
+    rs = c2.ResidentState.from_table(tab, nproma, ngptot)
+    ms = rs.nl(prm, repeats=3)
+    assert ms > 0.0
+    got = rs.download(c2.state_from_table(tab, nproma, ngptot, poison_outputs=3.0))
+    for n in ("PA", "PCOVPTOT", "PFPLSL", "PFPLSN", "PFHPSL", "PFHPSN", "B_LOC"):
+        assert np.array_equal(getattr(want, n), getattr(got, n)), n
+    # validate a field against a reference table made of its own first KLON columns: zero error, min/max of the field
+    cols = got.PFPLSN.transpose(0, 2, 1).reshape(-1, got.nlev + 1)[:100]  # (column, level)
+    st = rs.validate(B.F_FULL["PFPLSN"], np.ascontiguousarray(cols.T))
+    assert st[2] == 0.0 and st[3] == 0.0 and st[4] > 0.0
+    assert st[0] == got.PFPLSN.min() and st[1] == got.PFPLSN.max()
+
+    # the self-tests on the resident state vs. on host arrays
+    prm_tl = c2.default_params(c2.ceta_from_table(tab), lregcl=False)
+    zn_h, ok_h, it_h, _ = c2.run_state(prm_tl, c2.state_from_table(tab, nproma, ngptot), "tl")
+    zn_r, ok_r, it_r, _ = rs.tl_taylor(prm_tl)
+    assert np.array_equal(zn_h, zn_r) and ok_h == ok_r and it_h == it_r
+    prm_ad = c2.default_params(c2.ceta_from_table(tab), lregcl=True)
+    za_h, oka_h, _ = c2.run_state(prm_ad, c2.state_from_table(tab, nproma, ngptot), "ad")
+    za_r, oka_r, _ = rs.ad_symmetry(prm_ad)
+    assert za_h == za_r and oka_h and oka_r
+
+    rs2 = c2.ResidentState(nproma, tab["PT"].shape[0], ngptot)
+    rs2.ptsphy = rs.ptsphy
+    rs2.upload(c2.state_from_table(tab, nproma, ngptot))
+    rs2.nl(prm)
+    got2 = rs2.download(c2.state_from_table(tab, nproma, ngptot, poison_outputs=3.0))
+    assert np.array_equal(got2.B_LOC, want.B_LOC) and np.array_equal(got2.PFHPSN, want.PFHPSN)
+    with pytest.raises(c2.Cloudsc2Error):
+        rs.validate(99, np.zeros((138, 100)))

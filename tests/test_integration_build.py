@@ -24,7 +24,8 @@ def test_drivers_compile_against_the_reference_modules(tmp_path, prec):
     if not os.path.exists(os.path.join(refmods, "yomphyder.mod")):
         pytest.skip(f"{refmods} not built")
     flags = ["-cpp", "-O2", "-fPIC"] + (["-DSINGLE"] if prec == "sp" else [])
-    for src in ("cloudsc2_hip_mod.F90", "cloudsc_driver_mod.F90", "cloudsc_driver_tl_mod.F90", "cloudsc_driver_ad_mod.F90"):
+    # cloudsc_mpi_mod.F90 (RCCL) replaces the reference's module of the same name; the drivers below then USE it
+    for src in ("cloudsc_mpi_mod.F90", "cloudsc2_hip_mod.F90", "cloudsc_driver_mod.F90", "cloudsc_driver_tl_mod.F90", "cloudsc_driver_ad_mod.F90"):
         # our modules go to tmp_path (searched first); everything else they USE must come from the reference's build
         cmd = [FC, *flags, "-module-dir", str(tmp_path), "-I", str(tmp_path), "-I", refmods, "-c", os.path.join(FDIR, src),
                "-o", str(tmp_path / (src[:-4] + ".o"))]
@@ -35,4 +36,17 @@ def test_drivers_compile_against_the_reference_modules(tmp_path, prec):
     assert "cloudsc_driver" in nm and "cloudsc2_nl_run" in nm
     # none of the stand-in modules was used: they are not on the include path, and no .mod of them was produced
     produced = {f for f in os.listdir(tmp_path) if f.endswith(".mod")}
-    assert produced == {"cloudsc2_hip_mod.mod", "cloudsc_driver_mod.mod", "cloudsc_driver_tl_mod.mod", "cloudsc_driver_ad_mod.mod"}, produced
+    assert produced == {"cloudsc_mpi_mod.mod", "cloudsc2_hip_mod.mod", "cloudsc_driver_mod.mod", "cloudsc_driver_tl_mod.mod",
+                        "cloudsc_driver_ad_mod.mod"}, produced
+
+
+@pytest.mark.skipif(not os.path.exists(FC), reason="amdflang not installed")
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFMODS, "cloudsc_mpi_mod.mod")), reason="oracle/_ref/build not built")
+def test_drivers_also_compile_against_the_references_own_mpi_module(tmp_path):
+    """Without fortran/cloudsc_mpi_mod.F90 on the path the drivers pick up the REFERENCE's cloudsc_mpi_mod (the no-MPI build:
+    NUMPROC = 1, dummy reductions): a maintainer can adopt the HIP drivers first and the RCCL module later."""
+    for src in ("cloudsc2_hip_mod.F90", "cloudsc_driver_mod.F90", "cloudsc_driver_tl_mod.F90", "cloudsc_driver_ad_mod.F90"):
+        cmd = [FC, "-cpp", "-O2", "-fPIC", "-module-dir", str(tmp_path), "-I", str(tmp_path), "-I", REFMODS, "-c",
+               os.path.join(FDIR, src), "-o", str(tmp_path / (src[:-4] + ".o"))]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (" ".join(cmd), r.stderr[-3000:])
