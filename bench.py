@@ -376,10 +376,24 @@ def main():
             zad, _, _ = c2.run_state(c2.default_params(ceta, lregcl=True), vt, "ad")
             ztl_g = c2dist.allreduce_max(ztl, dev)
             zad_g = c2dist.allreduce_max([zad], dev)
+            # the same two reductions once more through the native boundary the Fortran mains use (libcloudsc2_comm.so:
+            # ncclAllReduce on a communicator bootstrapped by broadcasting the ncclUniqueId over torch.distributed)
+            native = {}
+            try:
+                from dwarf_p_cloudsc2_tl_ad_amd import comm as c2comm
+
+                _, _, transport = c2comm.init_from_torch(local, dev)
+                n_tl = c2comm.allreduce(ztl, c2comm.MAX)
+                n_ad = c2comm.allreduce([zad], c2comm.MAX)
+                c2comm.finalize()
+                native = {"transport": transport, "equals_torch_distributed": bool(np.array_equal(n_tl, ztl_g) and n_ad[0] == zad_g[0])}
+            except Exception as e:  # noqa: BLE001
+                native = {"error": repr(e)}
             tl_ok, itest = c2.binding.taylor_verdict(ztl_g)
             out["verdicts"] = {"backend": torch.distributed.get_backend(),
                                "tl_znormg": [float(x) for x in ztl_g], "tl_passed": bool(tl_ok), "tl_penalty": int(itest),
-                               "ad_symmetry_max_eps": float(zad_g[0]), "ad_ok": bool(c2.adjoint_verdict(float(zad_g[0])))}
+                               "ad_symmetry_max_eps": float(zad_g[0]), "ad_ok": bool(c2.adjoint_verdict(float(zad_g[0]))),
+                               "native_comm": native}
         except Exception as e:  # noqa: BLE001
             out["verdicts"] = {"error": repr(e)}
     if rank == 0:

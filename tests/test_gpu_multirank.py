@@ -45,9 +45,9 @@ def test_two_ranks_split_the_columns_and_reduce_the_statistics(tmp_path):
     assert err2.count("NUMPROC=2,") == 1             # rank 0 alone prints the header, and one table row per rank
     assert ": rank 0" in err2 and ": rank 1" in err2
     a, b = _summary(one), _summary(two)
-    for k in a:  # min and max exactly; the sums of |x| are added in another order
+    for k in a:  # min and max exactly; the sequential sums of 4e5 terms are added in another order
         assert a[k][0] == b[k][0] and a[k][1] == b[k][1], k
-        assert abs(a[k][2] - b[k][2]) <= 1e-12 * abs(a[k][2]), k
+        assert abs(a[k][2] - b[k][2]) <= 1e-10 * abs(a[k][2]), k
     assert two.count("Variable") == 1
 
 
@@ -96,7 +96,7 @@ def test_resident_mode_of_the_mains(tmp_path):
     one, _ = _run([exe, 1, 3000, 64], cwd=tmp_path)
     a, b = _summary(one), _summary(out)
     for k in a:
-        assert a[k][0] == b[k][0] and a[k][1] == b[k][1] and abs(a[k][2] - b[k][2]) <= 1e-12 * abs(a[k][2]), k
+        assert a[k][0] == b[k][0] and a[k][1] == b[k][1] and abs(a[k][2] - b[k][2]) <= 1e-10 * abs(a[k][2]), k
 
 
 def test_resident_validation_against_a_reference_file(tmp_path):
