@@ -240,8 +240,8 @@ def main():
         kname = "nl_kernel<F> (SATUR + CLOUDSC2 fused; fast math, no evaporation branch, 32-bit offsets when buffers < 4 GiB)"
     else:
         ds.satur(prm, stream)
-        inc = ds.increments(zero_supsat=(args.kernel == "ad"))
-        dout = c2.FlatFields("out", ds.nb, ds.nlev, ds.nproma, dev)
+        inc, dout = c2.FlatFields.pair(ds.nb, ds.nlev, ds.nproma, dev)  # increments + TL outputs, interleaved per block
+        ds.increments(zero_supsat=(args.kernel == "ad"), into=inc)
         if args.kernel == "tl":
             step, bpc, keep = (lambda: ds.tl(prm, inc, dout, stream)), c2.bytes_per_column(nlev, "tl"), (ds, inc, dout)
             kname = "tl_kernel<C2F_QSAT> (CLOUDSC2TL, trajectory recomputed, not stored)"

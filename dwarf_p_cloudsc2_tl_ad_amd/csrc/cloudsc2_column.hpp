@@ -123,6 +123,7 @@ struct RawLevel {
 #ifndef C2_NT_STORE
 #define C2_NT_STORE 1
 #endif
+
 C2_HD real_t ldg(const real_t* p, long long i) {
 #if C2_NT_LOAD && defined(__HIP_DEVICE_COMPILE__)
   return __builtin_nontemporal_load(p + i);
@@ -454,6 +455,10 @@ C2_HD void tl_column(long long gcol, TlArgsP a) {
   load_level<HAS_QSAT>(in, ol, nproma, nlev, 0, cur);
   load_level<true>(din, opl, nproma, nlev, 0, dcur);
 
+  // Both input sets of level jk+1 are requested at the top of level jk.  Measured alternatives (profiles/r02_ab_experiments.txt):
+  // requesting the perturbation inputs at the top of their own level (no second register set for them: 280 instead of 311
+  // registers) is 2 % slower, requesting the trajectory inputs between level_forward and level_tl 12 % slower, two levels of
+  // look-ahead 3 % slower at 160 000 columns and equal at 1 M: the full level of distance is what hides HBM latency here.
   for (int jk = 0; jk < nlev; ++jk) {
     const bool last = (jk == nlev - 1);
     TlArgsP ap = a;
@@ -528,13 +533,11 @@ C2_HD void ad_load_level(AdArgsP ap, const LaneOffT<OT>& o, const LaneOffT<OT>& 
     L.cur.gi = ldg(p.gi, o.cml + d);
     L.cur.supsat = ldg(p.supsat, o.full + d);
     if (HAS_QSAT) L.cur.qsat = ldg(p.qsat, o.full + d);
-  }
-  {
     const OutPtrs po = ap->nl.out;
     L.cy.rfl = ldg(po.fplsl, o.half + d);  // ZRFL5(JK) = PFPLSL5(JK)
     L.cy.sfl = ldg(po.fplsn, o.half + d);
+    L.cy.covptot = ldg(ap->nl.ckpt, osc + d);
   }
-  L.cy.covptot = ldg(ap->nl.ckpt, osc + d);
   const OutPtrs pa = ap->aout;
   L.ya.tent = ldg(pa.tent, oa.loc + d);
   L.ya.tenq = ldg(pa.tenq, oa.loc + d);
@@ -608,6 +611,8 @@ C2_HD void ad_reverse_column(long long gcol, AdArgsP a) {
     const OT d1 = d + row_off(OT(), nproma);
     AdArgsP ap = a;
     C2_LAUNDER(ap);
+    // all 44 loads of the level at its top; requesting the trajectory part (19 values) one level ahead was measured: +1.6 % time
+    // at 160 000 columns, -1 % at 1 M (profiles/r02_ab_experiments.txt)
     ad_load_level<HAS_QSAT, ASSIGN>(ap, ol, oa, osc, nproma, nlev, jk, L);
     RawLevel& cur = L.cur;
     cur.paph_k1 = paph_k1;

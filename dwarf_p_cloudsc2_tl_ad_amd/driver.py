@@ -85,23 +85,56 @@ def _fld(t, offset_elems: int, stride: int) -> B.Field:
 
 
 class FlatFields:
-    """16 input-shaped or 10 output-shaped flat (NBLOCKS, NLEVx, NPROMA) device arrays, e.g. the TL increments."""
+    """16 input-shaped or 10 output-shaped device arrays, e.g. the TL increments and the TL outputs: the thread-private scratch
+    arrays of the reference's test drivers (cloudsc_driver_tl_mod.F90:77-95) for all blocks at once.
 
-    def __init__(self, kind: str, nb: int, nlev: int, nproma: int, device, zero: bool = True):
-        import torch
+    FlatFields(kind, ...): separate (NBLOCKS, NLEVx, NPROMA) arrays, block stride NLEVx*NPROMA like the state's own arrays.
+    FlatFields.pair(...): the 16 inputs AND the 10 outputs of one perturbation / adjoint set; for NPROMA < 64 in ONE buffer
+    (NBLOCKS, 26, NLEV+1, NPROMA), field f of block b at plane f -- the AoSoA arrangement the reference itself uses for the
+    tendencies.  All 26 fields of a block then lie close together, and a wave's 26 streams share a few entries of the CU's
+    address-translation cache instead of occupying 26 (x 2 blocks per wave at NPROMA 32): with separate arrays the TL and AD
+    sweeps, which touch 53 and 64 streams per wave at one wave per SIMD, thrash it at small NPROMA (rocprofv3 TCP_UTCL1_*
+    counters, profiles/r02_utcl1_counters.txt).  The kernels see fields as pointer + block stride (one stride per layout group, the
+    perturbation inputs and outputs of a launch sharing theirs), so both arrangements go through the same launches."""
 
+    NPLANES = len(B.IN_NAMES) + len(B.OUT_NAMES)
+
+    def __init__(self, kind: str, nb: int, nlev: int, nproma: int, device, zero: bool = True, _views=None):
         self.kind = kind
         names = B.IN_NAMES if kind == "in" else B.OUT_NAMES
         half = {"paph"} if kind == "in" else {"fplsl", "fplsn", "fhpsl", "fhpsn"}
-        shapes = {n: (nb, nlev + (1 if n in half else 0), nproma) for n in names}
-        arena = B.DeviceArena(B.DeviceArena.size_of(shapes.values(), B.REAL_BYTES), device)  # one placed allocation
-        self.t = {n: arena.take(shp, zero=zero) for n, shp in shapes.items()}
+        if _views is not None:
+            buf, first = _views
+            self.buf = buf
+            self.t = {n: buf[:, first + k, : nlev + (1 if n in half else 0), :] for k, n in enumerate(names)}
+        else:
+            shapes = {n: (nb, nlev + (1 if n in half else 0), nproma) for n in names}
+            arena = B.DeviceArena(B.DeviceArena.size_of(shapes.values(), B.REAL_BYTES), device)  # one placed allocation
+            self.t = {n: arena.take(shp, zero=zero) for n, shp in shapes.items()}
         self.nlev, self.nproma = nlev, nproma
+
+    @classmethod
+    def pair(cls, nb: int, nlev: int, nproma: int, device, zero: bool = True):
+        """(inputs, outputs) of one perturbation / adjoint set, interleaved per block in one buffer (see the class docstring);
+        CLOUDSC2_SCRATCH_LAYOUT=flat gives two sets of separate arrays instead (A/B measurements)."""
+        import os
+
+        # NPROMA < 64: a wave spans two or more blocks (twice the streams): interleaved (TL 2.86 -> 1.66 ms, AD 4.07 -> 3.23 ms at
+        # NPROMA 32).  NPROMA >= 64: separate arrays are as fast (TL) or 4 % faster (AD).  The library's own test drivers follow
+        # the same rule (csrc/cloudsc2_driver.inc: pair_take).
+        layout = os.environ.get("CLOUDSC2_SCRATCH_LAYOUT") or ("blocked" if nproma < 64 else "flat")
+        if layout == "flat":
+            return cls("in", nb, nlev, nproma, device, zero), cls("out", nb, nlev, nproma, device, zero)
+        shape = (nb, cls.NPLANES, nlev + 1, nproma)
+        arena = B.DeviceArena(B.DeviceArena.size_of([shape], B.REAL_BYTES), device)
+        buf = arena.take(shape, zero=zero)
+        return (cls("in", nb, nlev, nproma, device, _views=(buf, 0)),
+                cls("out", nb, nlev, nproma, device, _views=(buf, len(B.IN_NAMES))))
 
     def block(self):
         blk = B.Inputs() if self.kind == "in" else B.Outputs()
         for n, t in self.t.items():
-            setattr(blk, n, _fld(t, 0, t.shape[1] * t.shape[2]))
+            setattr(blk, n, _fld(t, 0, t.stride(0)))
         return blk
 
     def zero_(self):
@@ -269,10 +302,10 @@ class DeviceState:
                                          C.byref(o), C.byref(ai), C.byref(ao), C.c_void_p(scratch.data_ptr()),
                                          self._stream(stream)))
 
-    def increments(self, zero_supsat: bool = False) -> FlatFields:
+    def increments(self, zero_supsat: bool = False, into: FlatFields | None = None) -> FlatFields:
         """dx = 0.01 * x for the 16 inputs (cloudsc_driver_tl_mod.F90:156-171); ZSUPSAT = 0 in the adjoint test
-        (cloudsc_driver_ad_mod.F90:139)."""
-        ff = FlatFields("in", self.nb, self.nlev, self.nproma, self.device, zero=False)
+        (cloudsc_driver_ad_mod.F90:139).  `into`: an existing input set (e.g. one half of FlatFields.pair) to fill."""
+        ff = into if into is not None else FlatFields("in", self.nb, self.nlev, self.nproma, self.device, zero=False)
         src = {"paph": self.PAPH, "pap": self.PAP, "q": self.PQ, "qsat": self.QSAT, "t": self.PT,
                "l": self.PCLV[:, 0], "i": self.PCLV[:, 1], "lude": self.PLUDE, "lu": self.PLU, "mfu": self.PMFU,
                "mfd": self.PMFD, "gtent": self.B_CML[:, PLANE_T], "gtenq": self.B_CML[:, PLANE_Q],

@@ -15,14 +15,15 @@ kind = sys.argv[1] if len(sys.argv) > 1 else "nl"
 ngptot = int(sys.argv[2]) if len(sys.argv) > 2 else 160000
 tab = c2.synthetic_table()
 prm = c2.default_params(c2.ceta_from_table(tab), lregcl=(kind == "ad"))
-ds = c2.DeviceState.from_table(tab, 128, ngptot)
+nproma = int(os.environ.get("NPROMA", "128"))
+ds = c2.DeviceState.from_table(tab, nproma, ngptot)
 info = dict(ds.arena.info) if hasattr(ds.arena, "info") else {}
 if kind == "nl":
     step = lambda: ds.nl(prm)  # noqa: E731
 else:
     ds.satur(prm)
-    inc = ds.increments(zero_supsat=(kind == "ad"))
-    dout = c2.FlatFields("out", ds.nb, ds.nlev, ds.nproma, ds.device)
+    inc, dout = c2.FlatFields.pair(ds.nb, ds.nlev, ds.nproma, ds.device)
+    ds.increments(zero_supsat=(kind == "ad"), into=inc)
     if kind == "tl":
         step = lambda: ds.tl(prm, inc, dout)  # noqa: E731
     else:

@@ -13,7 +13,7 @@ kernel = sys.argv[2] if len(sys.argv) > 2 else "nl"
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 tab = c2.synthetic_table()
 prm = c2.default_params(c2.ceta_from_table(tab), lregcl=True)
-ds = c2.DeviceState(c2.state_from_table(tab, 128, ngptot), "cuda:0")
+ds = c2.DeviceState.from_table(tab, int(os.environ.get("NPROMA", "128")), ngptot)
 if kernel == "nl":
     for _ in range(reps):
         ds.nl(prm)
