@@ -245,6 +245,7 @@ class DeviceArena:
         self.device = torch.device(device)
         self.nbytes = int(nbytes)
         self.used = 0
+        self.info = {}
         if STATE_ALLOC_TORCH:
             self.buf = None
             self.raw = torch.empty(max(self.nbytes, 1), dtype=torch.uint8, device=self.device)

@@ -99,7 +99,7 @@ class FlatFields:
 
     NPLANES = len(B.IN_NAMES) + len(B.OUT_NAMES)
 
-    def __init__(self, kind: str, nb: int, nlev: int, nproma: int, device, zero: bool = True, _views=None):
+    def __init__(self, kind: str, nb: int, nlev: int, nproma: int, device, zero: bool = True, _views=None, _arena=None):
         self.kind = kind
         names = B.IN_NAMES if kind == "in" else B.OUT_NAMES
         half = {"paph"} if kind == "in" else {"fplsl", "fplsn", "fhpsl", "fhpsn"}
@@ -109,12 +109,17 @@ class FlatFields:
             self.t = {n: buf[:, first + k, : nlev + (1 if n in half else 0), :] for k, n in enumerate(names)}
         else:
             shapes = {n: (nb, nlev + (1 if n in half else 0), nproma) for n in names}
-            arena = B.DeviceArena(B.DeviceArena.size_of(shapes.values(), B.REAL_BYTES), device)  # one placed allocation
+            arena = _arena or B.DeviceArena(B.DeviceArena.size_of(shapes.values(), B.REAL_BYTES), device)  # one placed allocation
             self.t = {n: arena.take(shp, zero=zero) for n, shp in shapes.items()}
         self.nlev, self.nproma = nlev, nproma
 
     @classmethod
-    def pair(cls, nb: int, nlev: int, nproma: int, device, zero: bool = True):
+    def pair_bytes(cls, nb: int, nlev: int, nproma: int) -> int:
+        """Bytes FlatFields.pair takes from an arena (either layout fits)."""
+        return B.DeviceArena.size_of([(nb, cls.NPLANES, nlev + 1, nproma)], B.REAL_BYTES) + 32 * B.DeviceArena.ALIGN
+
+    @classmethod
+    def pair(cls, nb: int, nlev: int, nproma: int, device, zero: bool = True, arena=None):
         """(inputs, outputs) of one perturbation / adjoint set, interleaved per block in one buffer (see the class docstring);
         CLOUDSC2_SCRATCH_LAYOUT=flat gives two sets of separate arrays instead (A/B measurements)."""
         import os
@@ -123,10 +128,11 @@ class FlatFields:
         # NPROMA 32).  NPROMA >= 64: separate arrays are as fast (TL) or 4 % faster (AD).  The library's own test drivers follow
         # the same rule (csrc/cloudsc2_driver.inc: pair_take).
         layout = os.environ.get("CLOUDSC2_SCRATCH_LAYOUT") or ("blocked" if nproma < 64 else "flat")
+        if arena is None:  # `arena`: carve the set out of an existing allocation (DeviceState.from_table(..., reserve=...))
+            arena = B.DeviceArena(cls.pair_bytes(nb, nlev, nproma), device)
         if layout == "flat":
-            return cls("in", nb, nlev, nproma, device, zero), cls("out", nb, nlev, nproma, device, zero)
+            return cls("in", nb, nlev, nproma, device, zero, _arena=arena), cls("out", nb, nlev, nproma, device, zero, _arena=arena)
         shape = (nb, cls.NPLANES, nlev + 1, nproma)
-        arena = B.DeviceArena(B.DeviceArena.size_of([shape], B.REAL_BYTES), device)
         buf = arena.take(shape, zero=zero)
         return (cls("in", nb, nlev, nproma, device, _views=(buf, 0)),
                 cls("out", nb, nlev, nproma, device, _views=(buf, len(B.IN_NAMES))))
@@ -147,6 +153,16 @@ class DeviceState:
 
     FULL = ("PT", "PQ", "PAP", "PLU", "PLUDE", "PMFU", "PMFD", "PA", "PSUPSAT", "PCOVPTOT")
     HALF = ("PAPH", "PFPLSL", "PFPLSN", "PFHPSL", "PFHPSN")
+    # what the sweeps write (cloudsc2.F90:135-149); inside the arena the read-only arrays come first, like in the library's own state
+    WRITTEN = ("PA", "PCOVPTOT", "PFPLSL", "PFPLSN", "PFHPSL", "PFHPSN", "B_LOC")
+
+    def _make_arenas(self, read_shapes, written_shapes, reserve: int = 0):
+        """The whole state in ONE placed allocation (cloudsc2_device_malloc), like the library's own (csrc/cloudsc2_driver.inc:
+        state_take): measured on one box, fresh processes, NL at 160 000 columns: 0.812 ms on 8 of 8, against 0.88-0.93 ms with
+        the written arrays placed and the read-only ones in a separate (plain or placed) allocation, and 0.90-0.96 ms without
+        placement (profiles/r02_placement/z_one_arena_vs_split.txt)."""
+        self.arena = B.DeviceArena(B.DeviceArena.size_of(list(read_shapes) + list(written_shapes), B.REAL_BYTES) + int(reserve), self.device)
+        self.arena_in = self.arena
 
     def __init__(self, st: Cloudsc2State, device="cuda:0"):
         import torch
@@ -156,11 +172,11 @@ class DeviceState:
         self.nproma, self.nlev, self.ngptot, self.ptsphy = st.nproma, st.nlev, st.ngptot, st.ptsphy
         self.nb = nblocks_of(st.ngptot, st.nproma)
         names = self.FULL + self.HALF + ("B_CML", "B_LOC", "PCLV")
-        shapes = [getattr(st, n).shape for n in names] + [st.PT.shape]
-        self.arena = B.DeviceArena(B.DeviceArena.size_of(shapes, B.REAL_BYTES), self.device)  # one placed allocation
+        self._make_arenas([getattr(st, n).shape for n in names if n not in self.WRITTEN],
+                          [getattr(st, n).shape for n in names if n in self.WRITTEN] + [st.PT.shape])
         for n in names:
             h = getattr(st, n)
-            d = self.arena.take(h.shape)
+            d = (self.arena if n in self.WRITTEN else self.arena_in).take(h.shape)
             d.copy_(torch.from_numpy(h))
             setattr(self, n, d)
         self.QSAT = self.arena.take(st.PT.shape, zero=True)
@@ -168,7 +184,7 @@ class DeviceState:
 
     @classmethod
     def from_table(cls, tab: dict, nproma: int, ngptot: int, device="cuda:0", start: int = 0, period: int | None = None,
-                   stream=None) -> "DeviceState":
+                   stream=None, reserve: int = 0) -> "DeviceState":
         """CLOUDSC2_ARRAY_STATE_LOAD (cloudsc2_array_state_mod.F90:153-203) without a host copy of the state: the
         KLON-column table is uploaded (a few MB) and tiled into the NPROMA-blocked arrays by cloudsc2_expand_launch;
         outputs are zero-initialised (FIELD_INIT, :186-190).  ``start``/``period``: binding.expand_offsets."""
@@ -183,15 +199,16 @@ class DeviceState:
         self._keep = []
         period = klon if period is None else period
         full, half = (self.nb, nlev, nproma), (self.nb, nlev + 1, nproma)
-        shapes = [full] * (len(self.FULL) + 1) + [half] * len(self.HALF) + [(self.nb, 8, nlev, nproma)] * 2 + [(self.nb, 5, nlev, nproma)]
-        self.arena = B.DeviceArena(B.DeviceArena.size_of(shapes, B.REAL_BYTES), self.device)  # one placed allocation
-        z = lambda *shape: self.arena.take(shape, zero=True)  # noqa: E731
-        for n in self.FULL:
-            setattr(self, n, z(*full))
-        for n in self.HALF:
-            setattr(self, n, z(*half))
-        self.B_CML, self.B_LOC, self.PCLV = z(self.nb, 8, nlev, nproma), z(self.nb, 8, nlev, nproma), z(self.nb, 5, nlev, nproma)
-        self.QSAT = z(*full)
+        shape_of = {n: full for n in self.FULL}
+        shape_of.update({n: half for n in self.HALF})
+        shape_of.update({"B_CML": (self.nb, 8, nlev, nproma), "B_LOC": (self.nb, 8, nlev, nproma), "PCLV": (self.nb, 5, nlev, nproma),
+                         "QSAT": full})
+        # `reserve` more bytes in the same allocation, e.g. FlatFields.pair_bytes(...) for a perturbation set that is to share the
+        # state's placement (FlatFields.pair(..., arena=ds.arena)), the way the library's own test drivers lay their scratch out
+        self._make_arenas([shp for n, shp in shape_of.items() if n not in self.WRITTEN and n != "QSAT"],
+                          [shp for n, shp in shape_of.items() if n in self.WRITTEN or n == "QSAT"], reserve)
+        for n, shp in shape_of.items():
+            setattr(self, n, (self.arena if (n in self.WRITTEN or n == "QSAT") else self.arena_in).take(shp, zero=True))
         S, H = nproma * nlev, nproma * (nlev + 1)
         jobs = [(n, getattr(self, n), 0, S if tab[n].shape[0] == nlev else H)
                 for n in ("PT", "PQ", "PAP", "PAPH", "PLU", "PLUDE", "PMFU", "PMFD", "PA", "PSUPSAT")]

@@ -16,6 +16,12 @@ cp("bench_default.json", "bench_default.json")
 cp("bench_prof.json", "bench_under_rocprof.json")
 cp("bench_prof_timed_region.json", "bench_under_rocprof_timed_region.json")
 shutil.copy(glob.glob(os.path.join(src, "prof", "*", "*kernel_stats.csv"))[0], os.path.join(dst, f"{prefix}_bench_kernel_stats.csv"))
+if os.path.exists(os.path.join(src, "bench_prof_1m.json")):  # the north_star target configuration under the profiler
+    cp("bench_prof_1m.json", "bench_1m_under_rocprof.json")
+    cp("bench_prof_1m_timed_region.json", "bench_1m_under_rocprof_timed_region.json")
+    shutil.copy(glob.glob(os.path.join(src, "prof_1m", "*", "*kernel_stats.csv"))[0], os.path.join(dst, f"{prefix}_bench_1m_kernel_stats.csv"))
+if os.path.exists(os.path.join(src, "pytest_gpu.log")):
+    cp("pytest_gpu.log", "pytest_gpu.log")
 for opt in ("rocm_smi_during_bench.txt", "single_checks_gpu.log"):
     if os.path.exists(os.path.join(src, opt)):
         cp(opt, opt)

@@ -16,19 +16,21 @@ ngptot = int(sys.argv[2]) if len(sys.argv) > 2 else 160000
 tab = c2.synthetic_table()
 prm = c2.default_params(c2.ceta_from_table(tab), lregcl=(kind == "ad"))
 nproma = int(os.environ.get("NPROMA", "128"))
-ds = c2.DeviceState.from_table(tab, nproma, ngptot)
+nbk = (ngptot + nproma - 1) // nproma
+one = os.environ.get("ONE_ARENA", "1") == "1" and kind != "nl"  # the perturbation set inside the state's own allocation
+ds = c2.DeviceState.from_table(tab, nproma, ngptot, reserve=(c2.FlatFields.pair_bytes(nbk, 137, nproma) + (nbk * 137 * nproma * 8 + 4096 if kind == "ad" else 0)) if one else 0)
 info = dict(ds.arena.info) if hasattr(ds.arena, "info") else {}
 if kind == "nl":
     step = lambda: ds.nl(prm)  # noqa: E731
 else:
     ds.satur(prm)
-    inc, dout = c2.FlatFields.pair(ds.nb, ds.nlev, ds.nproma, ds.device)
+    inc, dout = c2.FlatFields.pair(ds.nb, ds.nlev, ds.nproma, ds.device, arena=ds.arena if one else None)
     ds.increments(zero_supsat=(kind == "ad"), into=inc)
     if kind == "tl":
         step = lambda: ds.tl(prm, inc, dout)  # noqa: E731
     else:
         ds.tl(prm, inc, dout)
-        scratch = ds.new_scratch()
+        scratch = ds.arena.take((ds.nb, ds.nlev, ds.nproma)) if one else ds.new_scratch()
         step = lambda: ds.ad(prm, inc, dout, scratch)  # noqa: E731
 for _ in range(20):
     step()

@@ -19,8 +19,8 @@ if kernel == "nl":
         ds.nl(prm)
 else:
     ds.satur(prm)
-    inc = ds.increments()
-    dout = c2.FlatFields("out", ds.nb, ds.nlev, ds.nproma, ds.device)
+    inc, dout = c2.FlatFields.pair(ds.nb, ds.nlev, ds.nproma, ds.device)
+    ds.increments(into=inc)
     if kernel == "tl":
         for _ in range(reps):
             ds.tl(prm, inc, dout)
