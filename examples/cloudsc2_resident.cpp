@@ -56,13 +56,22 @@ int main(int argc, char** argv) {
   long long start = 0; int period = 0;
   cloudsc2_expand_offsets(klon, ngptot, 0, 0, 1, &start, &period);
 
-  // GLOBAL_STATE on the device (cloudsc2_array_state_mod.F90:26-79)
-  auto full = [&] { return dev_alloc((size_t)nblocks * S); };
-  auto half = [&] { return dev_alloc((size_t)nblocks * H); };
+  // GLOBAL_STATE on the device (cloudsc2_array_state_mod.F90:26-79): ONE allocation from the library's allocator, which places
+  // it for the sweeps' write streams (cloudsc2_device_malloc, include/cloudsc2_hip.h), carved into the arrays 256-byte aligned
+  auto r256 = [](size_t n) { return (n + 31) & ~(size_t)31; };  // doubles
+  const size_t nfull = r256((size_t)nblocks * S), nhalf = r256((size_t)nblocks * H);
+  const size_t total = 11 * nfull + 5 * nhalf + 2 * r256((size_t)nblocks * 8 * S) + r256((size_t)nblocks * 5 * S);
+  double* arena = nullptr;
+  C2_OK(cloudsc2_device_malloc((void**)&arena, total * sizeof(double)));
+  HIP_OK(hipMemset(arena, 0, total * sizeof(double)));
+  size_t used = 0;
+  auto take = [&](size_t n) { double* p = arena + used; used += r256(n); return p; };
+  auto full = [&] { return take((size_t)nblocks * S); };
+  auto half = [&] { return take((size_t)nblocks * H); };
   double *pt = full(), *pq = full(), *pap = full(), *paph = half(), *plu = full(), *plude = full(), *pmfu = full(),
          *pmfd = full(), *pa = full(), *psupsat = full(), *pcovptot = full(), *pfplsl = half(), *pfplsn = half(),
-         *pfhpsl = half(), *pfhpsn = half(), *b_cml = dev_alloc((size_t)nblocks * 8 * S), *b_loc = dev_alloc((size_t)nblocks * 8 * S),
-         *pclv = dev_alloc((size_t)nblocks * 5 * S);
+         *pfhpsl = half(), *pfhpsn = half(), *b_cml = take((size_t)nblocks * 8 * S), *b_loc = take((size_t)nblocks * 8 * S),
+         *pclv = take((size_t)nblocks * 5 * S);
   auto expand = [&](const char* name, int nlevx, int ndim, double* dst, long long stride) {
     double* tab = upload_table(fin, name, (size_t)klon * nlevx * ndim);
     C2_OK(cloudsc2_expand_launch(tab, klon, period, start, nlevx, ndim, nproma, ngptot, cloudsc2_field{dst, stride}, nullptr));
@@ -91,7 +100,8 @@ int main(int argc, char** argv) {
 
   hipEvent_t e0, e1;
   HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
-  C2_OK(cloudsc2_nl_launch(&prm, ptsphy, nproma, nlev, (int)ngptot, &in, &out, cloudsc2_field{b_loc + 7 * S, 8 * S}, 0.0, nullptr));  // warm-up
+  for (int w = 0; w < 10; ++w)  // warm-up (a fresh allocation needs a few launches to reach its steady time)
+    C2_OK(cloudsc2_nl_launch(&prm, ptsphy, nproma, nlev, (int)ngptot, &in, &out, cloudsc2_field{b_loc + 7 * S, 8 * S}, 0.0, nullptr));
   HIP_OK(hipEventRecord(e0, nullptr));
   C2_OK(cloudsc2_nl_launch(&prm, ptsphy, nproma, nlev, (int)ngptot, &in, &out, cloudsc2_field{b_loc + 7 * S, 8 * S}, 0.0, nullptr));
   HIP_OK(hipEventRecord(e1, nullptr));
@@ -131,5 +141,6 @@ int main(int argc, char** argv) {
     flagged += warn;
   }
   C2_OK(cloudsc2_file_close(fref));
+  C2_OK(cloudsc2_device_free(arena));
   return flagged ? 4 : 0;
 }
