@@ -124,6 +124,7 @@ struct RawLevel {
 #define C2_NT_STORE 1
 #endif
 
+
 C2_HD real_t ldg(const real_t* p, long long i) {
 #if C2_NT_LOAD && defined(__HIP_DEVICE_COMPILE__)
   return __builtin_nontemporal_load(p + i);
@@ -407,6 +408,8 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
     paph_k = cur.paph_k1;
   };
 
+  // (two levels of look-ahead with three register sets in rotation need 208 VGPRs, i.e. two waves per SIMD: 0.93 instead of 0.81 ms
+  // at 160 000 columns, equal at 1 M -- profiles/r02_ab_experiments.txt; with three waves it spills 148 bytes per lane)
   RawLevel ra, rb;
   load_level<HAS_QSAT>(in, ol, nproma, nlev, 0, ra);
   rb = ra;
