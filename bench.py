@@ -179,6 +179,9 @@ def main():
                          "NL target configuration, the unplaced first allocation")
     ap.add_argument("--precision", choices=["double", "single"], default=os.environ.get("CLOUDSC2_PRECISION", "double"),
                     help="single = the fp32 library (the reference's -DSINGLE build); the headline metric is double")
+    ap.add_argument("--ad-assign", action="store_true",
+                    help="--kernel ad: the assign form x = A^T y (cloudsc2_ad_launch_assign, what the adjoint test uses) instead of "
+                         "CLOUDSC2AD's accumulate form; its algorithmic bytes do not include reading the old input adjoints")
     ap.add_argument("--levapls2", action="store_true", help="switch the evaporation branch on (off in every shipped config)")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="no GPU work: start the ranks, rendezvous, shard the columns, reduce fake verdict norms, print the line "
@@ -202,6 +205,8 @@ def main():
     single = c2.binding.SINGLE
     fp = "fp32" if single else "fp64"
     variant = ", the -DSINGLE variant" if single else ""
+    if args.ad_assign and args.kernel == "ad":
+        variant += ", assign form of the adjoint"
 
     if args.rendezvous_only:
         rank, local, world = c2dist.init_process_group("gloo")
@@ -255,10 +260,13 @@ def main():
         else:
             ds.tl(prm, inc, dout, stream)
             scratch = ds.arena.take((ds.nb, ds.nlev, ds.nproma))
-            step = lambda: ds.ad(prm, inc, dout, scratch, stream)  # noqa: E731
+            step = lambda: ds.ad(prm, inc, dout, scratch, stream, assign=args.ad_assign)  # noqa: E731
             bpc = c2.bytes_per_column(nlev, "ad") + 2 * c2.binding.REAL_BYTES * nlev  # + carry checkpoint plane (write + read)
-            keep = (ds, inc, dout, scratch)
             kname = "ad_kernel<C2F_QSAT> (CLOUDSC2AD: trajectory pass + reverse pass)"
+            if args.ad_assign:  # the 16 old input adjoints (15 full-level planes + PAPH's nlev+1) are not read
+                bpc -= c2.binding.REAL_BYTES * (16 * nlev + 1)
+                kname = "ad_kernel<C2F_QSAT|C2F_ASSIGN> (x = A^T y: trajectory pass + reverse pass, old input adjoints not read)"
+            keep = (ds, inc, dout, scratch)
 
     def barrier():
         if torch.distributed.get_backend() == "nccl":
