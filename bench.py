@@ -321,6 +321,7 @@ def main():
     roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "bytes_per_column": bpc,
                 "algorithmic_bytes": bpc * args.ngptot, "kernel_ms_avg": k_avg, "kernel_ms_min": float(kms.min()),
+                "kernel_ms_first_tenth": float(kms[:max(1, len(kms) // 10)].mean()), "kernel_ms_last_tenth": float(kms[-max(1, len(kms) // 10):].mean()),
                 "kernel_ms_avg_per_rank": [round(x, 5) for x in k_per_rank],
                 "allocation": "first and only state of the process, from cloudsc2_device_malloc (placed by the library)"}
 

@@ -153,6 +153,8 @@ def _load() -> C.CDLL:
     lib.cloudsc2_device_free.argtypes = [C.c_void_p]
     lib.cloudsc2_device_malloc_info.argtypes = [C.POINTER(C.c_int), dp, dp, dp]
     lib.cloudsc2_device_malloc_info.restype = None
+    lib.cloudsc2_device_probe.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, dp]
+    lib.cloudsc2_device_probe.restype = C.c_int
     lib.cloudsc2_taylor_verdict.argtypes = [dp, C.POINTER(C.c_int)]
     lib.cloudsc2_adjoint_verdict.argtypes = [C.c_double]
     expand_args = [rp, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_longlong, Field]
@@ -186,7 +188,7 @@ EXPORTED = ("cloudsc2_params_default", "cloudsc2_last_error", "cloudsc2_device_a
             "cloudsc2_release_workspace", "cloudsc2_taylor_verdict", "cloudsc2_adjoint_verdict",
             "cloudsc2_expand_launch", "cloudsc2_validate_workspace_doubles", "cloudsc2_validate_launch",
             "cloudsc2_expand_offsets", "cloudsc2_validate_relerr", "cloudsc2_validate_format", "cloudsc2_validate_header",
-            "cloudsc2_device_malloc", "cloudsc2_device_free", "cloudsc2_device_malloc_info",
+            "cloudsc2_device_malloc", "cloudsc2_device_free", "cloudsc2_device_malloc_info", "cloudsc2_device_probe",
             "cloudsc2_state_create", "cloudsc2_state_destroy", "cloudsc2_state_field", "cloudsc2_state_expand",
             "cloudsc2_state_upload", "cloudsc2_state_download", "cloudsc2_state_nl", "cloudsc2_state_tl_taylor",
             "cloudsc2_state_ad_symmetry", "cloudsc2_state_validate")
@@ -217,6 +219,14 @@ class DeviceBuffer:
         if getattr(self, "ptr", 0):
             lib.cloudsc2_device_free(C.c_void_p(self.ptr))
             self.ptr = 0
+
+
+def device_probe(ptr: int, nbytes: int, kind: int = 0, rounds: int = 5) -> float:
+    """Diagnostic: median ms of the allocator's probe stream `kind` (0 writes, 1 the NL sweep's pattern) over the buffer, which it
+    overwrites (cloudsc2_device_probe)."""
+    ms = C.c_double()
+    check(lib.cloudsc2_device_probe(C.c_void_p(ptr), int(nbytes), int(kind), int(rounds), C.byref(ms)))
+    return ms.value
 
 
 def device_malloc_info() -> dict:

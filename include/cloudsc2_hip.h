@@ -97,6 +97,10 @@ int cloudsc2_get_math_mode(void);
 int cloudsc2_device_malloc(void** ptr, size_t bytes);
 void cloudsc2_device_malloc_info(int* candidates, double* best_ms, double* median_ms, double* worst_ms);
 int cloudsc2_device_free(void* ptr);
+/* Diagnostic: times one of the allocator's probe streams over [ptr, ptr+bytes) and OVERWRITES it.  kind 0: the sweeps' write
+ * stream (what the placement search uses); kind 1: the NL sweep's whole pattern -- 16 planes read, 11 written per level, the
+ * buffer taken as 27 planes.  *ms = median of `rounds` launches after one warm-up (tools/probe_vs_kernel.py). */
+int cloudsc2_device_probe(void* ptr, size_t bytes, int kind, int rounds, double* ms);
 
 /* ------------------------------------------------------------------------------------------------
  * Kernel level: DEVICE pointers, asynchronous on `stream` (a hipStream_t, NULL = default stream).
