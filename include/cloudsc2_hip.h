@@ -83,9 +83,9 @@ int cloudsc2_get_math_mode(void);
  * On MI355X write streams run 10-20 % slower into some parts of the HBM than into others, whatever the access pattern
  * (profiles/r02_hbm_placement.md): 0.81 vs 0.96 ms for the NL kernel at 160 000 columns, decided by where the OUTPUT arrays
  * happen to lie.  This allocator places what it hands out: for a request of 256 MiB or more it makes candidate allocations of
- * the full size -- enough of them to span 96 GiB together (12 to 64, never more than fit 60 % of the free memory) -- times the
- * sweeps' own write stream over each, keeps the fastest and frees the others (a few milliseconds per candidate, once per
- * allocation).  A request above 12 GiB (few whole candidates would fit) is composed instead: 2 GiB physical chunks are
+ * the full size -- enough of them to span 96 GiB together (12 to 64, never more than fit 60 % of the free memory) -- times two
+ * probe streams over each (the sweeps' write stream and the NL sweep's whole read/write pattern), keeps the candidate that is
+ * best on both and frees the others (about 10 ms per candidate, once per allocation).  A request above 12 GiB (few whole candidates would fit) is composed instead: 2 GiB physical chunks are
  * created and probed one by one, the fastest are mapped into one contiguous virtual range (hipMemCreate / hipMemMap) and the
  * others released.  Allocate a state -- inputs AND outputs -- as ONE request (an arena): that is what was measured to land in
  * the fast class 8 times of 8, whereas placing only the written arrays and leaving the inputs elsewhere does not (0.88-0.93 ms;

@@ -5,7 +5,7 @@
 tag=${1:-probe_ab}; it=${2:-5}; kernels=${3:-"nl tl"}; out=gpurun_out/$tag; mkdir -p $out
 run() {  # probe kernel ngptot
   if [ $1 = both ]; then unset CLOUDSC2_PLACE_PROBE; else export CLOUDSC2_PLACE_PROBE=$1; fi
-  CLOUDSC2_PLACE_VERBOSE=1 timeout -k 10 300 python bench.py --kernel $2 --ngptot $3 --steps 100 --warmup 3 --no-cpu-baseline --no-companions > $out/b.json 2>$out/err.log || { tail -3 $out/err.log; exit 1; }
+  CLOUDSC2_PLACE_VERBOSE=1 timeout -k 10 300 python bench.py --kernel $2 --ngptot $3 --steps ${STEPS:-100} --warmup 3 --no-cpu-baseline --no-companions > $out/b.json 2>$out/err.log || { tail -3 $out/err.log; exit 1; }
   python -c "import json; d=json.load(open('$out/b.json')); r=d['roofline']; print('$1 $2 $3 kernel ms avg', round(r['kernel_ms_avg'],4), 'first/last tenth', round(r['kernel_ms_first_tenth'],4), round(r['kernel_ms_last_tenth'],4))"
   grep "cloudsc2_device_malloc:" $out/err.log | cut -c1-420
 }
