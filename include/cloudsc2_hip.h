@@ -85,9 +85,10 @@ int cloudsc2_get_math_mode(void);
  * happen to lie.  This allocator places what it hands out: for a request of 256 MiB or more it makes candidate allocations of
  * the full size -- enough of them to span 96 GiB together (12 to 64, never more than fit 60 % of the free memory) -- times two
  * probe streams over each (the sweeps' write stream and the NL sweep's whole read/write pattern), keeps the candidate that is
- * best on both and frees the others (about 10 ms per candidate, once per allocation).  A request above 12 GiB (few whole candidates would fit) is composed instead: 2 GiB physical chunks are
- * created and probed one by one, the fastest are mapped into one contiguous virtual range (hipMemCreate / hipMemMap) and the
- * others released.  Allocate a state -- inputs AND outputs -- as ONE request (an arena): that is what was measured to land in
+ * best on both and frees the others (about 10 ms per candidate, once per allocation).  A request above 12 GiB (few whole
+ * candidates would fit) is composed instead: a pool of 2 GiB physical chunks is created (hipMemCreate), compositions of them are
+ * mapped one after the other into one contiguous virtual range (hipMemMap) and timed the same way, the best stays mapped and the
+ * other chunks are released.  Allocate a state -- inputs AND outputs -- as ONE request (an arena): that is what was measured to land in
  * the fast class 8 times of 8, whereas placing only the written arrays and leaving the inputs elsewhere does not (0.88-0.93 ms;
  * profiles/r02_placement/z_one_arena_vs_split.txt).  The pointer is ordinary device memory of the current device (kernels,
  * hipMemcpy; a composed range is not IPC-exportable); free it with cloudsc2_device_free, never with hipFree.  cloudsc2_device_malloc_info reports the last placement: number of
