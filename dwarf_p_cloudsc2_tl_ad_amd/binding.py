@@ -155,6 +155,8 @@ def _load() -> C.CDLL:
     lib.cloudsc2_device_malloc_info.restype = None
     lib.cloudsc2_device_probe.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, dp]
     lib.cloudsc2_device_probe.restype = C.c_int
+    lib.cloudsc2_device_malloc_state.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_int, C.c_int, C.c_int]
+    lib.cloudsc2_device_malloc_state.restype = C.c_int
     lib.cloudsc2_taylor_verdict.argtypes = [dp, C.POINTER(C.c_int)]
     lib.cloudsc2_adjoint_verdict.argtypes = [C.c_double]
     expand_args = [rp, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_longlong, Field]
@@ -188,7 +190,7 @@ EXPORTED = ("cloudsc2_params_default", "cloudsc2_last_error", "cloudsc2_device_a
             "cloudsc2_release_workspace", "cloudsc2_taylor_verdict", "cloudsc2_adjoint_verdict",
             "cloudsc2_expand_launch", "cloudsc2_validate_workspace_doubles", "cloudsc2_validate_launch",
             "cloudsc2_expand_offsets", "cloudsc2_validate_relerr", "cloudsc2_validate_format", "cloudsc2_validate_header",
-            "cloudsc2_device_malloc", "cloudsc2_device_free", "cloudsc2_device_malloc_info", "cloudsc2_device_probe",
+            "cloudsc2_device_malloc", "cloudsc2_device_free", "cloudsc2_device_malloc_info", "cloudsc2_device_probe", "cloudsc2_device_malloc_state",
             "cloudsc2_state_create", "cloudsc2_state_destroy", "cloudsc2_state_field", "cloudsc2_state_expand",
             "cloudsc2_state_upload", "cloudsc2_state_download", "cloudsc2_state_nl", "cloudsc2_state_tl_taylor",
             "cloudsc2_state_ad_symmetry", "cloudsc2_state_validate")
@@ -209,9 +211,12 @@ class DeviceBuffer:
     stream, include/cloudsc2_hip.h).  Exposes __cuda_array_interface__ so that torch can view it; freed with the last
     reference."""
 
-    def __init__(self, nbytes: int):
+    def __init__(self, nbytes: int, state_geom=None):
         p = C.c_void_p()
-        check(lib.cloudsc2_device_malloc(C.byref(p), int(nbytes)))
+        if state_geom is None:
+            check(lib.cloudsc2_device_malloc(C.byref(p), int(nbytes)))
+        else:  # (nproma, nlev, ngptot): a state of this geometry sits at the start; placement judged by the NL sweep itself
+            check(lib.cloudsc2_device_malloc_state(C.byref(p), int(nbytes), *[int(x) for x in state_geom]))
         self.ptr, self.nbytes = int(p.value or 0), int(nbytes)
         self.__cuda_array_interface__ = {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 2}
 
@@ -249,7 +254,7 @@ class DeviceArena:
 
     ALIGN = 256
 
-    def __init__(self, nbytes: int, device="cuda:0"):
+    def __init__(self, nbytes: int, device="cuda:0", state_geom=None):
         import torch
 
         self.device = torch.device(device)
@@ -261,7 +266,7 @@ class DeviceArena:
             self.raw = torch.empty(max(self.nbytes, 1), dtype=torch.uint8, device=self.device)
         else:
             with torch.cuda.device(self.device):
-                self.buf = DeviceBuffer(max(self.nbytes, 1))
+                self.buf = DeviceBuffer(max(self.nbytes, 1), state_geom)
                 self.raw = torch.as_tensor(self.buf, device=self.device)  # uint8 view; keeps `buf` alive
             self.info = device_malloc_info()
 

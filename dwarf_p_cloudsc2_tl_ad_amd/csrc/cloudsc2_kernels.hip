@@ -17,6 +17,7 @@
 #include <array>
 #include <atomic>
 #include <cmath>
+#include <functional>
 #include <initializer_list>
 #include <mutex>
 #include <stddef.h>

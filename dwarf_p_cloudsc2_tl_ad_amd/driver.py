@@ -156,12 +156,18 @@ class DeviceState:
     # what the sweeps write (cloudsc2.F90:135-149); inside the arena the read-only arrays come first, like in the library's own state
     WRITTEN = ("PA", "PCOVPTOT", "PFPLSL", "PFPLSN", "PFHPSL", "PFHPSN", "B_LOC")
 
+    # the order of the arrays inside the arena = the library's own (csrc/cloudsc2_driver.inc: state_take), which is what
+    # cloudsc2_device_malloc_state lays out in every candidate when it times the NL sweep on it
+    ORDER = ("PT", "PQ", "PAP", "PLU", "PLUDE", "PMFU", "PMFD", "PSUPSAT", "PAPH", "B_CML", "PCLV",
+             "PA", "PCOVPTOT", "QSAT", "PFPLSL", "PFPLSN", "PFHPSL", "PFHPSN", "B_LOC")
+
     def _make_arenas(self, read_shapes, written_shapes, reserve: int = 0):
         """The whole state in ONE placed allocation (cloudsc2_device_malloc), like the library's own (csrc/cloudsc2_driver.inc:
         state_take): measured on one box, fresh processes, NL at 160 000 columns: 0.812 ms on 8 of 8, against 0.88-0.93 ms with
         the written arrays placed and the read-only ones in a separate (plain or placed) allocation, and 0.90-0.96 ms without
         placement (profiles/r02_placement/z_one_arena_vs_split.txt)."""
-        self.arena = B.DeviceArena(B.DeviceArena.size_of(list(read_shapes) + list(written_shapes), B.REAL_BYTES) + int(reserve), self.device)
+        self.arena = B.DeviceArena(B.DeviceArena.size_of(list(read_shapes) + list(written_shapes), B.REAL_BYTES) + int(reserve), self.device,
+                                   state_geom=(self.nproma, self.nlev, self.ngptot))
         self.arena_in = self.arena
 
     def __init__(self, st: Cloudsc2State, device="cuda:0"):
@@ -171,15 +177,14 @@ class DeviceState:
         self.device = torch.device(device)
         self.nproma, self.nlev, self.ngptot, self.ptsphy = st.nproma, st.nlev, st.ngptot, st.ptsphy
         self.nb = nblocks_of(st.ngptot, st.nproma)
-        names = self.FULL + self.HALF + ("B_CML", "B_LOC", "PCLV")
-        self._make_arenas([getattr(st, n).shape for n in names if n not in self.WRITTEN],
-                          [getattr(st, n).shape for n in names if n in self.WRITTEN] + [st.PT.shape])
-        for n in names:
-            h = getattr(st, n)
-            d = (self.arena if n in self.WRITTEN else self.arena_in).take(h.shape)
-            d.copy_(torch.from_numpy(h))
+        shape_of = {n: (st.PT.shape if n == "QSAT" else getattr(st, n).shape) for n in self.ORDER}
+        self._make_arenas([shape_of[n] for n in self.ORDER if n not in self.WRITTEN and n != "QSAT"],
+                          [shape_of[n] for n in self.ORDER if n in self.WRITTEN or n == "QSAT"])
+        for n in self.ORDER:
+            d = self.arena.take(shape_of[n], zero=(n == "QSAT"))
+            if n != "QSAT":
+                d.copy_(torch.from_numpy(getattr(st, n)))
             setattr(self, n, d)
-        self.QSAT = self.arena.take(st.PT.shape, zero=True)
         self._keep = []
 
     @classmethod
@@ -205,10 +210,17 @@ class DeviceState:
                          "QSAT": full})
         # `reserve` more bytes in the same allocation, e.g. FlatFields.pair_bytes(...) for a perturbation set that is to share the
         # state's placement (FlatFields.pair(..., arena=ds.arena)), the way the library's own test drivers lay their scratch out
-        self._make_arenas([shp for n, shp in shape_of.items() if n not in self.WRITTEN and n != "QSAT"],
-                          [shp for n, shp in shape_of.items() if n in self.WRITTEN or n == "QSAT"], reserve)
-        for n, shp in shape_of.items():
-            setattr(self, n, (self.arena if (n in self.WRITTEN or n == "QSAT") else self.arena_in).take(shp, zero=True))
+        self._make_arenas([shape_of[n] for n in self.ORDER if n not in self.WRITTEN and n != "QSAT"],
+                          [shape_of[n] for n in self.ORDER if n in self.WRITTEN or n == "QSAT"], reserve)
+        trace = getattr(cls, "_trace", None)  # tools/one_process_series.py: a callable(state, stage) for timing between the stages
+        for n in self.ORDER:
+            setattr(self, n, self.arena.take(shape_of[n]))
+        if trace:
+            trace(self, "arrays carved out of the arena, nothing written yet")
+        for n in self.ORDER:
+            getattr(self, n).zero_()
+        if trace:
+            trace(self, "all arrays zeroed")
         S, H = nproma * nlev, nproma * (nlev + 1)
         jobs = [(n, getattr(self, n), 0, S if tab[n].shape[0] == nlev else H)
                 for n in ("PT", "PQ", "PAP", "PAPH", "PLU", "PLUDE", "PMFU", "PMFD", "PA", "PSUPSAT")]
@@ -220,6 +232,8 @@ class DeviceState:
             self._keep.append(src)
             B.check(B.lib.cloudsc2_expand_launch(C.cast(src.data_ptr(), _rp), klon, period, start,
                                                  src.shape[0], 1, nproma, ngptot, _fld(dst, off, stride), self._stream(stream)))
+        if trace:
+            trace(self, "table tiled into the arrays")
         return self
 
     def validate(self, ref: dict, ngptotg: int | None = None, start: int = 0, period: int | None = None, stream=None):

@@ -98,6 +98,15 @@ int cloudsc2_get_math_mode(void);
 int cloudsc2_device_malloc(void** ptr, size_t bytes);
 void cloudsc2_device_malloc_info(int* candidates, double* best_ms, double* median_ms, double* worst_ms);
 int cloudsc2_device_free(void* ptr);
+/* The same for a buffer that will hold a state of (nproma, nlev, ngptot) at its start (and whatever the caller keeps behind it:
+ * perturbation sets, scratch): the placement search times the NL kernel itself on a zero-filled state laid out in every candidate
+ * -- read-only arrays first (PT PQ PAP PLU PLUDE PMFU PMFD PSUPSAT PAPH B_CML PCLV), then what the sweeps write (PA PCOVPTOT QSAT
+ * PFPLSL PFPLSN PFHPSL PFHPSN B_LOC), each 256-byte aligned, the layout cloudsc2_state_* uses -- instead of the two generic probe
+ * streams, which stop predicting the kernel at 1 M columns (profiles/r02_placement/r_1m_probe_vs_kernel.txt).  When more than
+ * 256 MiB follow the state the two generic streams over the whole buffer judge instead (a buffer's speed is a property of the
+ * whole, and the NL sweep sees only its first part).  `bytes` must cover the state; the buffer comes back zero-filled only by
+ * accident, clear what you need.  Free with cloudsc2_device_free. */
+int cloudsc2_device_malloc_state(void** ptr, size_t bytes, int nproma, int nlev, int ngptot);
 /* Diagnostic: times one of the allocator's probe streams over [ptr, ptr+bytes) and OVERWRITES it.  kind 0: the sweeps' write
  * stream (what the placement search uses); kind 1: the NL sweep's whole pattern -- 16 planes read, 11 written per level, the
  * buffer taken as 27 planes.  *ms = median of `rounds` launches after one warm-up (tools/probe_vs_kernel.py). */

@@ -282,6 +282,29 @@ def test_resident_state_handle_equals_the_host_pointer_drivers():
         rs.validate(99, np.zeros((138, 100)))
 
 
+def test_state_allocation_is_judged_by_the_nl_sweep():
+    """cloudsc2_device_malloc_state: the candidates of a state's allocation are timed with the NL kernel itself on a state laid out
+    in each of them; the Python mirror's DeviceState lives in such an allocation, in the library's own array order, and computes the
+    same results as before (checked against the reference by the parity tests; here: against the flat host-side layout)."""
+    import ctypes as C
+
+    nproma, nlev, ngptot = 128, 137, 60000
+    nb = (ngptot + nproma - 1) // nproma
+    need = B.DeviceArena.size_of([(nb, nlev, nproma)] * 11 + [(nb, nlev + 1, nproma)] * 5 + [(nb, 8, nlev, nproma)] * 2 + [(nb, 5, nlev, nproma)],
+                                 B.REAL_BYTES)
+    p = C.c_void_p()
+    assert B.lib.cloudsc2_device_malloc_state(C.byref(p), need - 4096, nproma, nlev, ngptot) == B.CLOUDSC2_EINVAL  # too small for the state
+    buf = B.DeviceBuffer(need + (64 << 20), (nproma, nlev, ngptot))
+    info = B.device_malloc_info()
+    assert info["candidates"] >= 4 and info["probe_ms_best"] > 0.0
+    del buf
+    tab = c2.synthetic_table()
+    ds = c2.DeviceState.from_table(tab, nproma, ngptot, "cuda:0")
+    ptrs = [getattr(ds, n).data_ptr() for n in ds.ORDER]
+    assert ptrs == sorted(ptrs) and ptrs[0] == ds.arena.buf.ptr  # the library's order, from the start of the arena
+    assert ds.arena.info["candidates"] >= 4
+
+
 def test_device_allocator_places_and_frees():
     """cloudsc2_device_malloc / _free / _malloc_info (include/cloudsc2_hip.h): a large request is placed (several candidates probed),
     a small one is not, a foreign pointer is refused, and the memory is ordinary device memory."""
@@ -291,7 +314,8 @@ def test_device_allocator_places_and_frees():
 
     big = B.DeviceBuffer(3 << 30)
     info = B.device_malloc_info()
-    assert info["candidates"] >= 4 and 0.0 < info["probe_ms_best"] <= info["probe_ms_median"] <= info["probe_ms_worst"]
+    assert info["candidates"] >= 4 and 0.0 < info["probe_ms_best"] <= info["probe_ms_worst"] and info["probe_ms_median"] <= info["probe_ms_worst"]
+    assert B.device_probe(big.ptr, big.nbytes, 0, 3) > 0.0 and B.device_probe(big.ptr, big.nbytes, 1, 3) > 0.0  # the diagnostic streams
     t = torch.as_tensor(big, device="cuda:0")
     t[:1024].fill_(7)
     assert int(t[:1024].sum().item()) == 7 * 1024
