@@ -56,22 +56,24 @@ int main(int argc, char** argv) {
   long long start = 0; int period = 0;
   cloudsc2_expand_offsets(klon, ngptot, 0, 0, 1, &start, &period);
 
-  // GLOBAL_STATE on the device (cloudsc2_array_state_mod.F90:26-79): ONE allocation from the library's allocator, which places
-  // it for the sweeps' write streams (cloudsc2_device_malloc, include/cloudsc2_hip.h), carved into the arrays 256-byte aligned
+  // GLOBAL_STATE on the device (cloudsc2_array_state_mod.F90:26-79): ONE allocation from the library's allocator, which places it
+  // (cloudsc2_device_malloc_state, include/cloudsc2_hip.h: candidates are judged by the NL sweep on a state in the layout below --
+  // read-only arrays first, then what the sweeps write, each 256-byte aligned)
   auto r256 = [](size_t n) { return (n + 31) & ~(size_t)31; };  // doubles
   const size_t nfull = r256((size_t)nblocks * S), nhalf = r256((size_t)nblocks * H);
   const size_t total = 11 * nfull + 5 * nhalf + 2 * r256((size_t)nblocks * 8 * S) + r256((size_t)nblocks * 5 * S);
   double* arena = nullptr;
-  C2_OK(cloudsc2_device_malloc((void**)&arena, total * sizeof(double)));
+  C2_OK(cloudsc2_device_malloc_state((void**)&arena, total * sizeof(double), nproma, nlev, (int)ngptot));
   HIP_OK(hipMemset(arena, 0, total * sizeof(double)));
   size_t used = 0;
   auto take = [&](size_t n) { double* p = arena + used; used += r256(n); return p; };
   auto full = [&] { return take((size_t)nblocks * S); };
   auto half = [&] { return take((size_t)nblocks * H); };
-  double *pt = full(), *pq = full(), *pap = full(), *paph = half(), *plu = full(), *plude = full(), *pmfu = full(),
-         *pmfd = full(), *pa = full(), *psupsat = full(), *pcovptot = full(), *pfplsl = half(), *pfplsn = half(),
-         *pfhpsl = half(), *pfhpsn = half(), *b_cml = take((size_t)nblocks * 8 * S), *b_loc = take((size_t)nblocks * 8 * S),
-         *pclv = take((size_t)nblocks * 5 * S);
+  double *pt = full(), *pq = full(), *pap = full(), *plu = full(), *plude = full(), *pmfu = full(), *pmfd = full(), *psupsat = full(),
+         *paph = half(), *b_cml = take((size_t)nblocks * 8 * S), *pclv = take((size_t)nblocks * 5 * S);
+  double *pa = full(), *pcovptot = full(), *qsat_unused = full(), *pfplsl = half(), *pfplsn = half(), *pfhpsl = half(), *pfhpsn = half(),
+         *b_loc = take((size_t)nblocks * 8 * S);
+  (void)qsat_unused;  // SATUR is fused into the NL sweep; the slot keeps the layout the library's own state has
   auto expand = [&](const char* name, int nlevx, int ndim, double* dst, long long stride) {
     double* tab = upload_table(fin, name, (size_t)klon * nlevx * ndim);
     C2_OK(cloudsc2_expand_launch(tab, klon, period, start, nlevx, ndim, nproma, ngptot, cloudsc2_field{dst, stride}, nullptr));

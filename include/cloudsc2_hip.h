@@ -82,16 +82,14 @@ int cloudsc2_get_math_mode(void);
 /* Device memory for callers that keep the state resident (and what the library uses for its own buffers).
  * On MI355X write streams run 10-20 % slower into some parts of the HBM than into others, whatever the access pattern
  * (profiles/r02_hbm_placement.md): 0.81 vs 0.96 ms for the NL kernel at 160 000 columns, decided by where the OUTPUT arrays
- * happen to lie.  This allocator places what it hands out: for a request of 256 MiB or more it makes candidate allocations of
- * the full size -- enough of them to span 96 GiB together (12 to 64, never more than fit 60 % of the free memory) -- times two
- * probe streams over each (the sweeps' write stream and the NL sweep's whole read/write pattern), keeps the candidate that is
- * best on both and frees the others (about 10 ms per candidate, once per allocation).  A request above 12 GiB (few whole
- * candidates would fit) is composed instead: a pool of 2 GiB physical chunks is created (hipMemCreate), compositions of them are
- * mapped one after the other into one contiguous virtual range (hipMemMap) and timed the same way, the best stays mapped and the
- * other chunks are released.  Allocate a state -- inputs AND outputs -- as ONE request (an arena): that is what was measured to land in
+ * happen to lie.  This allocator places what it hands out: for a request of 256 MiB or more it makes candidate hipMalloc
+ * allocations of the full size -- enough of them to span 96 GiB together (12 to 64, never more than fit 60 % of the free memory;
+ * 85 % for requests above 12 GiB) -- times two probe streams over each (the sweeps' write stream and the NL sweep's whole
+ * read/write pattern), keeps the best and frees the others (about 10 ms per candidate, once per allocation).
+ * Allocate a state -- inputs AND outputs -- as ONE request (an arena): that is what was measured to land in
  * the fast class 8 times of 8, whereas placing only the written arrays and leaving the inputs elsewhere does not (0.88-0.93 ms;
- * profiles/r02_placement/z_one_arena_vs_split.txt).  The pointer is ordinary device memory of the current device (kernels,
- * hipMemcpy; a composed range is not IPC-exportable); free it with cloudsc2_device_free, never with hipFree.  cloudsc2_device_malloc_info reports the last placement: number of
+ * profiles/r02_placement/z_one_arena_vs_split.txt).  The pointer is ordinary hipMalloc memory of the current device; free it with
+ * cloudsc2_device_free.  cloudsc2_device_malloc_info reports the last placement: number of
  * candidates and the probe time of the best, the median and the worst of them (0 when there was no choice).
  * There is no reference counterpart: the reference's arrays are host ALLOCATABLEs (cloudsc2_array_state_mod.F90:97-151). */
 #include <stddef.h>
