@@ -378,6 +378,7 @@ def main():
         cb = cpu_baseline(tab, prm, 32, args.ngptot)
         if cb:
             out["cpu_baseline"] = cb
+    native_hung = False
     if world > 1:
         # The only inter-GPU exchange of the path: max-reduce the two self-tests' verdict norms (outside the timing).  Each rank
         # runs the Taylor test and the adjoint test on its own 1024-column sub-range; ZNORMG(10) and ZNORMG are all-reduced
@@ -394,17 +395,31 @@ def main():
             zad_g = c2dist.allreduce_max([zad], dev)
             # the same two reductions once more through the native boundary the Fortran mains use (libcloudsc2_comm.so:
             # ncclAllReduce on a communicator bootstrapped by broadcasting the ncclUniqueId over torch.distributed)
+            # -- in a thread with a deadline, so that a communicator that never comes up cannot take the JSON line with it
             native = {}
-            try:
-                from dwarf_p_cloudsc2_tl_ad_amd import comm as c2comm
 
-                _, _, transport = c2comm.init_from_torch(local, dev)
-                n_tl = c2comm.allreduce(ztl, c2comm.MAX)
-                n_ad = c2comm.allreduce([zad], c2comm.MAX)
-                c2comm.finalize()
-                native = {"transport": transport, "equals_torch_distributed": bool(np.array_equal(n_tl, ztl_g) and n_ad[0] == zad_g[0])}
-            except Exception as e:  # noqa: BLE001
-                native = {"error": repr(e)}
+            def native_reductions():
+                try:
+                    from dwarf_p_cloudsc2_tl_ad_amd import comm as c2comm
+
+                    torch.cuda.set_device(dev)
+                    _, _, transport = c2comm.init_from_torch(local, dev)
+                    n_tl = c2comm.allreduce(ztl, c2comm.MAX)
+                    n_ad = c2comm.allreduce([zad], c2comm.MAX)
+                    c2comm.finalize()
+                    native.update({"transport": transport,
+                                   "equals_torch_distributed": bool(np.array_equal(n_tl, ztl_g) and n_ad[0] == zad_g[0])})
+                except Exception as e:  # noqa: BLE001
+                    native.update({"error": repr(e)})
+
+            import threading
+
+            th = threading.Thread(target=native_reductions, daemon=True)
+            th.start()
+            th.join(120.0)
+            if th.is_alive():
+                native = {"error": "no answer within 120 s"}
+                native_hung = True
             tl_ok, itest = c2.binding.taylor_verdict(ztl_g)
             out["verdicts"] = {"backend": torch.distributed.get_backend(),
                                "tl_znormg": [float(x) for x in ztl_g], "tl_passed": bool(tl_ok), "tl_penalty": int(itest),
@@ -414,6 +429,9 @@ def main():
             out["verdicts"] = {"error": repr(e)}
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if native_hung:  # a thread of this rank still sits in the native communicator: leave without the orderly shutdown
+        sys.stdout.flush()
+        os._exit(0)
     if world > 1:
         torch.distributed.destroy_process_group()
 
