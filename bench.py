@@ -276,7 +276,8 @@ def main():
 
     for _ in range(max(args.warmup, 0)):
         step()
-    for _ in range(15):  # a fresh allocation needs ~10 launches to reach its steady time; not counted as warm-up steps W
+    for _ in range(15):  # after an idle second the GPU needs ~15 launches (12 ms) to reach its steady time again, whatever the memory
+        # (tools/settle_series.py: 0.93 0.84 0.86 0.89 0.87 ... 0.82 ms; the same after a 2 s pause); not counted as warm-up steps W
         step()
     torch.cuda.synchronize(dev)
     if world > 1:
