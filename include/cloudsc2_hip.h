@@ -86,6 +86,8 @@ int cloudsc2_get_math_mode(void);
  * allocations of the full size -- enough of them to span 96 GiB together (12 to 64, never more than fit 60 % of the free memory;
  * 85 % for requests above 12 GiB) -- times two probe streams over each (the sweeps' write stream and the NL sweep's whole
  * read/write pattern), keeps the best and frees the others (about 10 ms per candidate, once per allocation).
+ * The mixed stream reads the first 59 % of the buffer and writes the last 41 %: put what your sweeps WRITE at the end of the
+ * buffer (a sweep that wrote at 23-39 % of a buffer placed this way ran at 5.0 instead of 5.8 TB/s).
  * Allocate a state -- inputs AND outputs -- as ONE request (an arena): that is what was measured to land in
  * the fast class 8 times of 8, whereas placing only the written arrays and leaving the inputs elsewhere does not (0.88-0.93 ms;
  * profiles/r02_placement/z_one_arena_vs_split.txt).  The pointer is ordinary hipMalloc memory of the current device; free it with
