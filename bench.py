@@ -324,7 +324,14 @@ def main():
                 "algorithmic_bytes": bpc * args.ngptot, "kernel_ms_avg": k_avg, "kernel_ms_min": float(kms.min()),
                 "kernel_ms_first_tenth": float(kms[:max(1, len(kms) // 10)].mean()), "kernel_ms_last_tenth": float(kms[-max(1, len(kms) // 10):].mean()),
                 "kernel_ms_avg_per_rank": [round(x, 5) for x in k_per_rank],
-                "allocation": "first and only state of the process, from cloudsc2_device_malloc (placed by the library)"}
+                "allocation": "first and only state of the process, from cloudsc2_device_malloc_state (placed by the library)"}
+    if args.kernel == "nl" and placement.get("candidates", 0) > 1 and not os.environ.get("CLOUDSC2_PLACE_PROBE"):
+        # a state alone is judged by the NL sweep itself (zero-filled state in every candidate), so the allocator's probe times ARE
+        # kernel times: what the median and the worst candidate of this box would have given
+        roofline["candidates"] = {"count": placement["candidates"], "judge": "NL sweep on a zero-filled state in each candidate",
+                                  "kernel_ms_chosen": placement["probe_ms_best"], "kernel_ms_median": placement["probe_ms_median"],
+                                  "kernel_ms_worst": placement["probe_ms_worst"],
+                                  "frac_median_candidate": bpc * args.ngptot / (placement["probe_ms_median"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
     out = {
         "metric": f"CLOUDSC2 {args.kernel.upper()} columns/sec ({fp}, NLEV=137)", "value": value, "unit": "columns/s",
