@@ -29,7 +29,11 @@ for it in range(n):
     want = ref_nl_state(chk, st, prm)
     got = st.copy()
     c2.run_state(prm, got, "nl")
-    assert_outputs_close(want, got, NL_TOL)
+    # random atmospheres: ten times the suite's NL tolerance -- the fast arithmetic's few ulp are amplified where the cloud cover
+    # saturates (seen: 2.2e-12 in PA at cover 0.987 with LREGCL, 3.6e-14 in precise arithmetic: tools/fuzz_case.py 38 777); a
+    # flipped branch would show at 1e-6 or more
+    assert_outputs_close(want, got, 10 * NL_TOL)
+    worst["nl"] = max(worst["nl"], max(relerr(r, got.outputs()[k]) for k, r in want.outputs().items()))
     r = _device_tl_ad(tab, nproma, ngptot, flags)
     act = lambda a: np.concatenate([a[ibl][:, : min(nproma, ngptot - ibl * nproma)] for ibl in range(st.nblocks)], axis=1)  # noqa: E731
     e_tl = max(relerr(act(r["tl_ref"][k]), act(r["tl_dev"][k])) for k in r["tl_ref"])
@@ -41,4 +45,4 @@ for it in range(n):
     assert e_tl <= TLAD_TOL and e_ad <= TLAD_TOL, (it, e_tl, e_ad)
     worst["tl"], worst["ad"] = max(worst["tl"], e_tl), max(worst["ad"], e_ad)
     print(f"case {it:2d}: nlev {nlev:3d} nproma {nproma:3d} ngptot {ngptot:4d} {flags}  tl {e_tl:.1e} ad {e_ad:.1e}", flush=True)
-print("FUZZ PASSED", n, "cases; worst tl", f"{worst['tl']:.2e}", "ad", f"{worst['ad']:.2e}")
+print("FUZZ PASSED", n, "cases; worst nl", f"{worst['nl']:.2e}", "tl", f"{worst['tl']:.2e}", "ad", f"{worst['ad']:.2e}")
