@@ -7,7 +7,8 @@ split); there is no collective in the data path.  Prints ONE JSON line (rank 0).
 the N ranks itself; under `python -m torch.distributed.run` it uses the launcher's ranks.
 
 The state is the first and only allocation of the process and comes from the library's allocator, which places it
-(cloudsc2_device_malloc; profiles/r02_hbm_placement.md): bench.py does not search.  `roofline.unplaced_first_allocation`
+(cloudsc2_device_malloc_state: candidate allocations judged by the NL sweep itself; profiles/r02_hbm_placement.md): bench.py does
+not search.  `roofline.unplaced_first_allocation`
 is the same measurement in a fresh process with the placement switched off.
 
 The line also carries `cpu_baseline` (the reference on the host cores, rank 0 at N=1) and, at N=1, from child processes run
@@ -234,9 +235,9 @@ def main():
     stream = torch.cuda.current_stream(dev)
 
     # The state: tiled on the device from the 100-column table (cloudsc2_expand_launch: no host copy exists) into ONE arena
-    # from the library's allocator, which places it (cloudsc2_device_malloc: the fastest of up to 12 candidate allocations
-    # for the sweeps' write stream, profiles/r02_hbm_placement.md).  This is the first and only state of the process: what
-    # any caller of the C ABI gets, no search here.
+    # from the library's allocator, which places it (cloudsc2_device_malloc_state: candidate allocations spanning 96 GiB, judged by
+    # the NL sweep itself for a state alone, by two generic streams when perturbation sets follow; profiles/r02_hbm_placement.md).
+    # This is the first and only state of the process: what any caller of the C ABI gets, no search here.
     # TL / AD: the perturbation set (increments + outputs) and the adjoint's carry plane live in the SAME allocation as the state,
     # as in the library's own test drivers (measured: TL 1.65 vs 1.66-1.72 ms, AD 3.04 vs 3.18-3.22 ms for a separate allocation)
     nbk = (args.ngptot + args.nproma - 1) // args.nproma

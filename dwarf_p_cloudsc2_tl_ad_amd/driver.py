@@ -162,10 +162,11 @@ class DeviceState:
              "PA", "PCOVPTOT", "QSAT", "PFPLSL", "PFPLSN", "PFHPSL", "PFHPSN", "B_LOC")
 
     def _make_arenas(self, read_shapes, written_shapes, reserve: int = 0):
-        """The whole state in ONE placed allocation (cloudsc2_device_malloc), like the library's own (csrc/cloudsc2_driver.inc:
+        """The whole state in ONE placed allocation (cloudsc2_device_malloc_state), like the library's own (csrc/cloudsc2_driver.inc:
         state_take): measured on one box, fresh processes, NL at 160 000 columns: 0.812 ms on 8 of 8, against 0.88-0.93 ms with
         the written arrays placed and the read-only ones in a separate (plain or placed) allocation, and 0.90-0.96 ms without
-        placement (profiles/r02_placement/z_one_arena_vs_split.txt)."""
+        placement (profiles/r02_placement/z_one_arena_vs_split.txt).  The allocator judges its candidates by the NL sweep on a state
+        in exactly this layout (by two generic streams when `reserve` puts perturbation sets behind the state)."""
         self.arena = B.DeviceArena(B.DeviceArena.size_of(list(read_shapes) + list(written_shapes), B.REAL_BYTES) + int(reserve), self.device,
                                    state_geom=(self.nproma, self.nlev, self.ngptot))
         self.arena_in = self.arena
