@@ -409,7 +409,11 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
   };
 
   // (two levels of look-ahead with three register sets in rotation need 208 VGPRs, i.e. two waves per SIMD: 0.93 instead of 0.81 ms
-  // at 160 000 columns, equal at 1 M -- profiles/r02_ab_experiments.txt; with three waves it spills 148 bytes per lane)
+  // at 160 000 columns, equal at 1 M -- profiles/r02_ab_experiments.txt; with three waves it spills 148 bytes per lane.  TOUCHING the
+  // rows of level jk+2 instead -- one plain 32-bit load per lane and plane, 16 dwords held for a level, 167 VGPRs, no spill -- so that
+  // the lines are in L2 / the Infinity Cache when the real load comes: 0.92 instead of 0.82 ms, 5.94 instead of 4.90 ms at 1 M; the
+  // sweep is limited by the requests it makes, not by their latency.  What the physics costs on top of its own memory pattern, with
+  // the state placed alike: -DC2_SKELETON 0.769 ms against 0.818 at 160 000 columns (6 %), 4.93 against 4.98 at 1 M (1 %).)
   RawLevel ra, rb;
   load_level<HAS_QSAT>(in, ol, nproma, nlev, 0, ra);
   rb = ra;
