@@ -102,3 +102,22 @@ def test_bench_cpu_baseline_leg_runs():
     cb = bench.cpu_baseline(tab, prm, 32, 2000, budget_s=0.5)
     assert cb is not None and cb["unit"] == "columns/s" and cb["kind"] in ("reference", "port")
     assert cb["value"] > 0 and cb["numomp4_value"] > 0 and cb["cores"] >= 1
+
+
+def test_device_state_layout_lists_every_array_once_in_the_librarys_order():
+    """DeviceState.ORDER is the order in which the arrays are carved out of the state's allocation; it has to be the library's own
+    (csrc/cloudsc2_driver.inc: state_take), because cloudsc2_device_malloc_state judges its candidates by running the NL sweep on a
+    state laid out that way: read-only arrays first, then everything the sweeps write."""
+    import re
+
+    from dwarf_p_cloudsc2_tl_ad_amd.driver import DeviceState
+
+    names = set(DeviceState.FULL) | set(DeviceState.HALF) | {"B_CML", "B_LOC", "PCLV", "QSAT"}
+    assert len(DeviceState.ORDER) == len(set(DeviceState.ORDER)) == len(names) and set(DeviceState.ORDER) == names
+    written = [n for n in DeviceState.ORDER if n in DeviceState.WRITTEN or n == "QSAT"]
+    assert DeviceState.ORDER[-len(written):] == tuple(written)  # what the sweeps write lies at the end of the allocation
+    src = open(os.path.join(ROOT, "dwarf_p_cloudsc2_tl_ad_amd", "csrc", "cloudsc2_driver.inc")).read()
+    body = src[src.index("void state_take("):]
+    body = body[:body.index("\n}\n")]
+    lib_order = [m.upper() for m in re.findall(r"d\.(\w+) = a(?:in|out)\.take", body)]
+    assert lib_order == [n.upper() for n in DeviceState.ORDER], (lib_order, DeviceState.ORDER)
