@@ -61,6 +61,51 @@ __global__ void __launch_bounds__(kNproma) k8(const double* __restrict__ base, d
   }
 }
 
+// k8 with arithmetic between the loads and the stores of a level, as much as the NL physics has (NFMA dependent-chain FMAs on 8
+// accumulators per level ~ NFMA vector instructions): what does a level's compute cost on top of the memory pattern, and does a
+// second level of look-ahead (DEPTH 2, registers) buy it back at the same occupancy?
+template <int DEPTH, int NFMA>
+__global__ void __launch_bounds__(kNproma) kcomp(const double* __restrict__ base, double* __restrict__ wbase, long long plane_elems) {
+  extern __shared__ double lds[];
+  const long long off = (long long)blockIdx.x * kLevPad * kNproma + threadIdx.x;
+  const double* in = base + off;
+  double* out = wbase + off;
+  double buf[DEPTH + 1][kIn];
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+    for (int p = 0; p < kIn; ++p) buf[d][p] = __builtin_nontemporal_load(in + p * plane_elems + d * kNproma);
+  double carry = 0.0;
+#pragma unroll 1
+  for (int jk0 = 0; jk0 < kLev; jk0 += DEPTH + 1) {
+#pragma unroll
+    for (int s = 0; s <= DEPTH; ++s) {
+      const int jk = jk0 + s;
+      if (jk < kLev) {
+        const int slot_new = (s + DEPTH) % (DEPTH + 1);
+        if (jk + DEPTH < kLev) {
+#pragma unroll
+          for (int p = 0; p < kIn; ++p) buf[slot_new][p] = __builtin_nontemporal_load(in + p * plane_elems + (jk + DEPTH) * kNproma);
+        }
+        double a[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = buf[s][i] + carry;
+#pragma unroll 1
+        for (int it = 0; it < NFMA / 8; ++it) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) a[i] = fma(a[i], buf[s][8 + i], 1.0e-3);
+        }
+        double acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc += a[i];
+        carry = acc * 1.0e-9;
+#pragma unroll
+        for (int q = 0; q < kOut; ++q) __builtin_nontemporal_store(acc + q, out + q * plane_elems + jk * kNproma);
+      }
+    }
+  }
+}
+
 // the same sweep with the plane counts of the other kernels (TL: 32 read / 20 written per level; AD reverse sweep: 44 / 26)
 template <int NIN, int NOUT>
 __global__ void __launch_bounds__(kNproma) kshape(const double* __restrict__ base, double* __restrict__ wbase, long long plane_elems) {
@@ -179,7 +224,27 @@ int main(int argc, char** argv) {
              t16, useful / t16 / 1e9);
       fflush(stdout);
     }
-  if (shapes) {
+  if (argc > 2 && atoi(argv[2]) == 2) {  // arithmetic between loads and stores: 0 / 280 / 560 / 1120 FMAs per level, look-ahead 1 and 2
+    CHECK(hipFuncSetAttribute((const void*)kcomp<1, 280>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    CHECK(hipFuncSetAttribute((const void*)kcomp<1, 560>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    CHECK(hipFuncSetAttribute((const void*)kcomp<1, 1120>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    CHECK(hipFuncSetAttribute((const void*)kcomp<2, 280>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    CHECK(hipFuncSetAttribute((const void*)kcomp<2, 560>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    CHECK(hipFuncSetAttribute((const void*)kcomp<2, 1120>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    const size_t lds3 = 26 * 1024;  // three waves per SIMD, like the NL kernel
+#define RUN(K) median_ms([&] { hipLaunchKernelGGL((K), dim3((unsigned)nblk), dim3(kNproma), lds3, 0, base, wbase, plane_elems); }, 15)
+    for (int round = 0; round < 3; ++round) {
+      double t0 = RUN(k8<1>), u0 = RUN(k8<2>);
+      double t1 = RUN((kcomp<1, 280>)), u1 = RUN((kcomp<2, 280>));
+      double t2 = RUN((kcomp<1, 560>)), u2 = RUN((kcomp<2, 560>));
+      double t3 = RUN((kcomp<1, 1120>)), u3 = RUN((kcomp<2, 1120>));
+      printf("3 waves/SIMD, FMAs per level 0 / 280 / 560 / 1120: look-ahead 1: %.4f %.4f %.4f %.4f ms | look-ahead 2: %.4f %.4f %.4f %.4f ms\n", t0, t1, t2, t3, u0, u1,
+             u2, u3);
+      fflush(stdout);
+    }
+#undef RUN
+  }
+  if (shapes && atoi(argv[2]) == 1) {
     // each shape in an allocation of its own size, placed by the library: where in a buffer the WRITTEN planes lie decides its speed
     // (a sweep over the first 27 planes of a 70-plane buffer placed as a whole ran at 4.95 TB/s where the whole ran at 5.75)
     CHECK(hipFuncSetAttribute((const void*)kshape<16, 11>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
