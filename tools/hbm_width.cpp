@@ -5,6 +5,9 @@
 //   k8d2 : the same with two levels in flight
 //   k16  : a level-pair-interleaved layout (NPROMA,2,NLEV/2,NBLOCKS): 16 bytes per lane and request, one pair ahead
 // each at 2, 3 and "as many as fit" waves per SIMD (occupancy limited with dynamic LDS).
+// usage: hbm_width NGPTOT        the three forms above
+//        hbm_width NGPTOT 1      + the plane counts of TL (32 read / 20 written) and of the AD reverse sweep (44 / 26), one placed buffer each
+//        hbm_width NGPTOT 2      + arithmetic between a level's loads and stores (0 / 280 / 560 / 1120 FMAs), look-ahead 1 and 2
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -o tools/bin/hbm_width tools/hbm_width.cpp \
 //          -L dwarf_p_cloudsc2_tl_ad_amd/csrc -lcloudsc2_hip -Wl,-rpath,$PWD/dwarf_p_cloudsc2_tl_ad_amd/csrc
 #include <hip/hip_runtime.h>
