@@ -30,6 +30,40 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+SETTLE_LAUNCHES = 15   # untimed launches after the --warmup ones (the GPU's clocks settle; reported in the line)
+
+
+def select_pmc_traffic(pdir, kernel, ngptot, real_bytes, algorithmic_bytes):
+    """HBM traffic of one launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*pmc_traffic.json, written by
+    tools/pmc_parse.py).  The pass is chosen by its CONTENT -- `real_bytes` (precision), `ngptot` (launch size), the kernel's
+    entry and the algorithmic bytes it was taken with (a pass of an older form of the kernel is stale) -- never by its file
+    name; the newest round's file wins among equals.  A figure below the algorithmic bytes is impossible for this path (every
+    plane element is moved at least once) and is rejected.  Returns (bytes or None, dict of fields for the line)."""
+    cands = []
+    for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if not f.endswith("pmc_traffic.json"):
+            continue
+        try:
+            d = json.load(open(os.path.join(pdir, f)))
+            k = d["kernels"][kernel]
+            n = int(d["ngptot"])
+            if int(d["real_bytes"]) != int(real_bytes):
+                continue
+            if abs(float(k["algorithmic_bytes"]) / n * ngptot - algorithmic_bytes) > 1e-6 * algorithmic_bytes:
+                continue  # taken when the kernel moved other bytes
+            cands.append((n == int(ngptot), f, float(k["traffic_bytes"]) / n * ngptot))
+        except (KeyError, ValueError, TypeError, OSError):
+            continue  # older files without the fields, other kernels
+    if not cands:
+        return None, {"traffic_source": None}
+    cands.sort(key=lambda c: (c[0], c[1]))  # same launch size first, then the newest file name (rNN_ prefixes sort by round)
+    same, fname, traffic = cands[-1]
+    info = {"traffic_source": f"profiles/{fname} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run, "
+                              f"{'same' if same else 'another'} launch size, scaled per column; not measured in this run)"}
+    if traffic < 0.999 * algorithmic_bytes:
+        info["traffic_rejected"] = f"{traffic:.4g} B is below the algorithmic {algorithmic_bytes:.4g} B"
+        return None, info
+    return traffic, info
 
 
 def effective_cores() -> int:
@@ -128,28 +162,95 @@ def free_port() -> int:
     return port
 
 
-def spawn_ranks(ngpus: int, argv) -> int:
-    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) of this same script and
-    relay rank 0's JSON line.  Runs before anything in this process has touched the GPU or imported torch; the children get
-    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* exactly as `python -m torch.distributed.run --nproc-per-node N` would set
-    them, so both ways of starting the bench run the same code."""
-    import subprocess
+def visible_gpus() -> int:
+    """GPUs this process could use, WITHOUT initialising HIP (device_count does not, on this image)."""
+    try:
+        import torch
 
+        return int(torch.cuda.device_count())
+    except Exception:  # noqa: BLE001
+        return 0
+
+
+def _tail(path, n=2000):
+    try:
+        with open(path, "rb") as f:
+            f.seek(0, 2)
+            size = f.tell()
+            f.seek(max(0, size - n))
+            return f.read().decode("utf-8", "replace")
+    except OSError:
+        return ""
+
+
+def spawn_ranks(ngpus: int, argv, rehearsal: bool = False) -> int:
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) of this same script and
+    relay rank 0's JSON line.  Runs before anything in this process has touched the GPU; the children get
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* exactly as `python -m torch.distributed.run --nproc-per-node N` would set
+    them, so both ways of starting the bench run the same code.
+
+    The launch cannot die silently (the reference's ranks are MPI processes: one failing rank aborts the job,
+    dwarf_cloudsc.F90:57-69): every rank's stderr goes to bench_rank<r>.err, all children are polled, the first non-zero
+    exit terminates the others within seconds and its stderr tail is relayed, an overall deadline bounds the run, and nothing
+    is restarted or re-exec'ed."""
+    import subprocess
+    import tempfile
+
+    if not rehearsal and os.environ.get("CLOUDSC2_DIST_BACKEND", "") != "gloo":
+        have = visible_gpus()
+        if have < ngpus:
+            print(f"bench.py: --gpus {ngpus} but only {have} GPU(s) are visible; nothing started "
+                  "(CLOUDSC2_DIST_BACKEND=gloo rehearses the multi-rank path on fewer GPUs)", file=sys.stderr)
+            return 2
+    logdir = os.environ.get("CLOUDSC2_BENCH_LOGDIR") or tempfile.mkdtemp(prefix="cloudsc2_bench_")
+    os.makedirs(logdir, exist_ok=True)
+    deadline = time.monotonic() + float(os.environ.get("CLOUDSC2_BENCH_DEADLINE_S", "1500"))
     env = dict(os.environ, WORLD_SIZE=str(ngpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), LOCAL_WORLD_SIZE=str(ngpus))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL needs it)
-    procs = []
+    procs, errs = [], []
+    out0 = os.path.join(logdir, "bench_rank0.out")
     for r in range(ngpus):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [p.wait() for p in procs]
-    lines = [ln for ln in (out0 or "").splitlines() if ln.strip()]
+        errs.append(os.path.join(logdir, f"bench_rank{r}.err"))
+        with open(errs[r], "wb") as ferr, open(out0 if r == 0 else os.devnull, "wb") as fout:
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e, stdout=fout, stderr=ferr))
+
+    def stop_all():
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_kill = time.monotonic() + 5.0
+        for p in procs:
+            try:
+                p.wait(max(0.1, t_kill - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+
+    failed, why = None, None
+    while True:
+        rcs = [p.poll() for p in procs]
+        bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad:
+            failed, why = bad, "exit code"
+            break
+        if all(rc == 0 for rc in rcs):
+            break
+        if time.monotonic() > deadline:
+            failed, why = [(r, None) for r, rc in enumerate(rcs) if rc is None], "still running at the deadline (CLOUDSC2_BENCH_DEADLINE_S)"
+            break
+        time.sleep(0.2)
+    if failed:
+        stop_all()
+    lines = [ln for ln in _tail(out0, 1 << 20).splitlines() if ln.strip().startswith("{")]
     if lines:
         print(lines[-1], flush=True)
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad or not lines:
-        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+    if failed or not lines:
+        print(f"bench.py: launch of {ngpus} ranks failed -- (rank, exit code) {failed}: {why}; per-rank stderr in {logdir}", file=sys.stderr)
+        for r, _ in (failed or [(0, None)])[:2]:
+            tail = _tail(errs[r]).strip()
+            if tail:
+                print(f"---- rank {r} stderr (tail) ----\n{tail}", file=sys.stderr)
         return 1
     return 0
 
@@ -193,9 +294,13 @@ def main():
         raise SystemExit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ:
         if args.gpus > 1:  # no launcher: become one (nothing here has touched the GPU yet)
-            raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+            raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:], rehearsal=args.rendezvous_only))
     elif int(os.environ["WORLD_SIZE"]) != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
+
+    if os.environ.get("CLOUDSC2_BENCH_FAIL_RANK") == os.environ.get("RANK", "0"):  # tests/test_bench_launch.py: a rank that dies at start
+        print("bench.py: this rank was told to fail at start (CLOUDSC2_BENCH_FAIL_RANK)", file=sys.stderr)
+        raise SystemExit(3)
 
     import torch
 
@@ -277,8 +382,9 @@ def main():
 
     for _ in range(max(args.warmup, 0)):
         step()
-    for _ in range(15):  # after an idle second the GPU needs ~15 launches (12 ms) to reach its steady time again, whatever the memory
-        # (tools/settle_series.py: 0.93 0.84 0.86 0.89 0.87 ... 0.82 ms; the same after a 2 s pause); not counted as warm-up steps W
+    for _ in range(SETTLE_LAUNCHES):  # after an idle second the GPU needs ~15 launches (12 ms) to reach its steady time again, whatever the memory
+        # (tools/settle_series.py: 0.93 0.84 0.86 0.89 0.87 ... 0.82 ms; the same after a 2 s pause); reported as `settle_launches`,
+        # next to the W warm-up steps the caller asked for (`warmup_total` = both)
         step()
     torch.cuda.synchronize(dev)
     if world > 1:
@@ -307,21 +413,11 @@ def main():
     # HBM traffic: NOT measured in this run.  It is the figure of the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
     # separate runs, calibrated as the MI355X guide prescribes; tools/pmc_workload.py + tools/pmc_parse.py), scaled per column
     # to this launch; `traffic_source` names the file, null if there is none for this precision.
-    traffic, traffic_source = None, None
-    pdir = os.path.join(ROOT, "profiles")
-    pmc_files = sorted(f for f in os.listdir(pdir) if f.endswith("pmc_traffic.json")) if os.path.isdir(pdir) else []
-    pmc_files = [f for f in pmc_files if ("_sp_" in f) == single]  # counters are per precision
-    if pmc_files:
-        try:
-            pmcs = [(f, json.load(open(os.path.join(pdir, f)))) for f in pmc_files]
-            same = [p for p in pmcs if p[1].get("ngptot") == args.ngptot]  # prefer the pass taken at this launch size
-            fname, pmc = (same or pmcs)[-1]
-            traffic = pmc["kernels"][args.kernel]["traffic_bytes"] / pmc["ngptot"] * args.ngptot
-            traffic_source = f"profiles/{fname} (rocprofv3 --pmc passes of an earlier run, scaled per column; not measured in this run)"
-        except (KeyError, ValueError, OSError):
-            traffic, traffic_source = None, None
+    tkey = "ad_assign" if (args.kernel == "ad" and args.ad_assign) else args.kernel
+    traffic, tinfo = select_pmc_traffic(os.path.join(ROOT, "profiles"), tkey, args.ngptot, c2.binding.REAL_BYTES, bpc * args.ngptot)
     roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "bytes_per_column": bpc,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_over_algorithmic": (traffic / (bpc * args.ngptot)) if traffic else None, **tinfo, "bytes_per_column": bpc,
                 "algorithmic_bytes": bpc * args.ngptot, "kernel_ms_avg": k_avg, "kernel_ms_min": float(kms.min()),
                 "kernel_ms_first_tenth": float(kms[:max(1, len(kms) // 10)].mean()), "kernel_ms_last_tenth": float(kms[-max(1, len(kms) // 10):].mean()),
                 "kernel_ms_avg_per_rank": [round(x, 5) for x in k_per_rank],
@@ -336,7 +432,8 @@ def main():
 
     out = {
         "metric": f"CLOUDSC2 {args.kernel.upper()} columns/sec ({fp}, NLEV=137)", "value": value, "unit": "columns/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_launches": SETTLE_LAUNCHES,
+        "warmup_total": max(args.warmup, 0) + SETTLE_LAUNCHES, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if single else "f64", "data": "synthetic",
         "config": {"workload": f"CLOUDSC2 {args.kernel.upper()} {fp}, NGPTOT={args.ngptot} columns per GPU, NLEV=137, "
                                f"NPROMA={args.nproma} (BASELINE.json configs[1]{variant})",
@@ -440,7 +537,7 @@ def main():
         print(json.dumps(out), flush=True)
     if native_hung:  # a thread of this rank still sits in the native communicator: leave without the orderly shutdown
         sys.stdout.flush()
-        os._exit(0)
+        os._exit(3)  # the line is out, but a communicator that never answered is a failed run
     if world > 1:
         torch.distributed.destroy_process_group()
 

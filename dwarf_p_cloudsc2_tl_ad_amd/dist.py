@@ -36,7 +36,12 @@ def init_process_group(backend: str | None = None):
             torch.cuda.set_device(local)
         elif torch.cuda.is_available():
             local = local % max(torch.cuda.device_count(), 1)  # rehearsal: ranks share the GPUs that exist
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        # explicit deadline: a rank that never shows up fails the rendezvous (and every later collective) after this long
+        # instead of torch's default half hour -- the launcher then sees a non-zero exit and stops the job
+        import datetime
+
+        timeout = datetime.timedelta(seconds=float(os.environ.get("CLOUDSC2_DIST_TIMEOUT_S", "300")))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
     return rank, local, world
 
 

@@ -30,6 +30,56 @@ def test_gpus_flag_starts_that_many_ranks():
     assert abs(d["verdicts"]["tl_znormg"][0] - 1.3) < 1e-12 and d["verdicts"]["ad_znormg"] == 7.0
 
 
+def test_a_rank_that_dies_at_start_fails_the_launch_within_seconds():
+    """One rank exits 3 before the rendezvous: the parent stops the others (they would sit in the rendezvous until its
+    timeout), exits non-zero, names the rank and relays its stderr -- nothing is restarted (VERDICT r02 weak #10)."""
+    import time
+
+    t0 = time.monotonic()
+    r = _run(["--gpus", 3, "--rendezvous-only", "--ngptot", 1000], env={"CLOUDSC2_BENCH_FAIL_RANK": "1"}, timeout=120)
+    dt = time.monotonic() - t0
+    assert r.returncode != 0, r.stdout
+    assert dt < 30.0, dt
+    assert "(1, 3)" in r.stderr and "told to fail at start" in r.stderr, r.stderr[-2000:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.strip()]  # no line from a failed launch
+
+
+def test_the_launch_has_an_overall_deadline():
+    """All ranks healthy but slower than the deadline: the parent kills them and fails instead of hanging."""
+    r = _run(["--gpus", 2, "--rendezvous-only"], env={"CLOUDSC2_BENCH_DEADLINE_S": "0.01"}, timeout=120)
+    assert r.returncode != 0 and "deadline" in r.stderr, r.stderr[-2000:]
+
+
+def test_more_ranks_than_gpus_is_refused_before_anything_starts():
+    import torch
+
+    if torch.cuda.device_count() >= 64:
+        import pytest
+
+        pytest.skip("a box with 64 GPUs")
+    r = _run(["--gpus", 64, "--steps", 1], env={"CLOUDSC2_DIST_BACKEND": ""})
+    assert r.returncode == 2 and "nothing started" in r.stderr, r.stderr[-2000:]
+
+
+def test_pmc_traffic_is_chosen_by_content_not_by_file_name():
+    """The fp64 headline line once carried the fp32 library's traffic because of a file-name filter (VERDICT r02 weak #5)."""
+    import bench
+
+    pdir = os.path.join(ROOT, "profiles")
+    for rb, per_col in ((8, 28536), (4, 14268)):
+        for n in (160000, 1048576):
+            algo = per_col * n
+            traffic, info = bench.select_pmc_traffic(pdir, "nl", n, rb, algo)
+            assert traffic is not None and "same launch size" in info["traffic_source"], info
+            assert algo <= traffic < 1.1 * algo, (rb, n, traffic / algo)
+            d = json.load(open(os.path.join(ROOT, info["traffic_source"].split(" ")[0])))
+            assert d["real_bytes"] == rb and d["ngptot"] == n
+    # a pass taken with other algorithmic bytes (an older form of the kernel) is stale: null, never a wrong figure
+    traffic, info = bench.select_pmc_traffic(pdir, "nl", 160000, 8, 20000 * 160000)
+    assert traffic is None and info["traffic_source"] is None
+    assert bench.select_pmc_traffic(os.path.join(ROOT, "no_such_dir"), "nl", 160000, 8, 1)[0] is None
+
+
 def test_a_launcher_with_another_world_size_is_refused():
     r = _run(["--gpus", 4, "--rendezvous-only"], env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
