@@ -284,6 +284,9 @@ def main():
     ap.add_argument("--ad-assign", action="store_true",
                     help="--kernel ad: the assign form x = A^T y (cloudsc2_ad_launch_assign, what the adjoint test uses) instead of "
                          "CLOUDSC2AD's accumulate form; its algorithmic bytes do not include reading the old input adjoints")
+    ap.add_argument("--ad-sweep", choices=["both", "reverse"], default="both",
+                    help="--kernel ad: reverse = the reverse sweep alone (cloudsc2_ad_launch_reverse) on the PFPLSL5 / PFPLSN5 an earlier "
+                         "sweep left in the state -- the adjoint leg of cloudsc2_ad_symmetry_run")
     ap.add_argument("--levapls2", action="store_true", help="switch the evaporation branch on (off in every shipped config)")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="no GPU work: start the ranks, rendezvous, shard the columns, reduce fake verdict norms, print the line "
@@ -313,6 +316,8 @@ def main():
     variant = ", the -DSINGLE variant" if single else ""
     if args.ad_assign and args.kernel == "ad":
         variant += ", assign form of the adjoint"
+    if args.ad_sweep == "reverse" and args.kernel == "ad":
+        variant += ", reverse sweep alone"
 
     if args.rendezvous_only:
         rank, local, world = c2dist.init_process_group("gloo")
@@ -349,7 +354,7 @@ def main():
     nlev_t = tab["PT"].shape[0]
     reserve = 0
     if args.kernel != "nl":
-        reserve = c2.FlatFields.pair_bytes(nbk, nlev_t, args.nproma) + (nbk * nlev_t * args.nproma * c2.binding.REAL_BYTES + 4096 if args.kernel == "ad" else 0)
+        reserve = c2.FlatFields.pair_bytes(nbk, nlev_t, args.nproma) + (nbk * nlev_t * args.nproma * c2.binding.REAL_BYTES + 4096 if (args.kernel == "ad" and args.levapls2) else 0)
     ds = c2.DeviceState.from_table(tab, args.nproma, args.ngptot, dev, start=col0, reserve=reserve)
     placement = dict(getattr(ds.arena, "info", {}))
     nlev = ds.nlev
@@ -364,14 +369,18 @@ def main():
             step, bpc, keep = (lambda: ds.tl(prm, inc, dout, stream)), c2.bytes_per_column(nlev, "tl"), (ds, inc, dout)
             kname = "tl_kernel<C2F_QSAT> (CLOUDSC2TL, trajectory recomputed, not stored)"
         else:
-            ds.tl(prm, inc, dout, stream)
-            scratch = ds.arena.take((ds.nb, ds.nlev, ds.nproma))
-            step = lambda: ds.ad(prm, inc, dout, scratch, stream, assign=args.ad_assign)  # noqa: E731
-            bpc = c2.bytes_per_column(nlev, "ad") + 2 * c2.binding.REAL_BYTES * nlev  # + carry checkpoint plane (write + read)
-            kname = "ad_kernel<C2F_QSAT> (CLOUDSC2AD: trajectory pass + reverse pass)"
+            ds.tl(prm, inc, dout, stream)  # leaves the trajectory outputs (PFPLSL5 / PFPLSN5) in the state
+            # the cover-checkpoint plane exists only with the evaporation branch (its one reader)
+            scratch = ds.arena.take((ds.nb, ds.nlev, ds.nproma)) if args.levapls2 else None
+            step = lambda: ds.ad(prm, inc, dout, scratch, stream, assign=args.ad_assign, sweep=args.ad_sweep)  # noqa: E731
+            bpc = c2.bytes_per_column(nlev, "ad" if args.ad_sweep == "both" else "ad_reverse")
+            if args.levapls2:  # + the checkpoint plane: written by the forward sweep, read by the reverse sweep
+                bpc += c2.bytes_per_column(nlev, "ad_ckpt") // (1 if args.ad_sweep == "both" else 2)
+            kname = ("ad_kernel<C2F_QSAT> (CLOUDSC2AD: trajectory pass + reverse pass)" if args.ad_sweep == "both" else
+                     "ad_reverse_kernel<C2F_QSAT> (reverse sweep of CLOUDSC2AD alone; carries from the state's PFPLSL5 / PFPLSN5)")
             if args.ad_assign:  # the 16 old input adjoints (15 full-level planes + PAPH's nlev+1) are not read
-                bpc -= c2.binding.REAL_BYTES * (16 * nlev + 1)
-                kname = "ad_kernel<C2F_QSAT|C2F_ASSIGN> (x = A^T y: trajectory pass + reverse pass, old input adjoints not read)"
+                bpc -= c2.bytes_per_column(nlev, "ad_old_adjoints")
+                kname = kname.replace("<C2F_QSAT>", "<C2F_QSAT|C2F_ASSIGN>") + " [x = A^T y: old input adjoints not read]"
             keep = (ds, inc, dout, scratch)
 
     def barrier():
@@ -413,7 +422,9 @@ def main():
     # HBM traffic: NOT measured in this run.  It is the figure of the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
     # separate runs, calibrated as the MI355X guide prescribes; tools/pmc_workload.py + tools/pmc_parse.py), scaled per column
     # to this launch; `traffic_source` names the file, null if there is none for this precision.
-    tkey = "ad_assign" if (args.kernel == "ad" and args.ad_assign) else args.kernel
+    tkey = args.kernel
+    if args.kernel == "ad":
+        tkey = ("ad" if args.ad_sweep == "both" else "ad_reverse") + ("_assign" if args.ad_assign else "")
     traffic, tinfo = select_pmc_traffic(os.path.join(ROOT, "profiles"), tkey, args.ngptot, c2.binding.REAL_BYTES, bpc * args.ngptot)
     roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

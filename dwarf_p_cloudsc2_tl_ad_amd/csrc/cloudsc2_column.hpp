@@ -50,7 +50,9 @@ struct InPtrsRW {
 struct NlArgs {
   Consts c; Geom g; Strides s; InPtrs in; OutPtrs out; const LevelTab* tab;
   real_t* zero_plane; long long zero_stride; real_t lam;
-  real_t* ckpt;  // CKPT kernels only: (NPROMA,NLEV,NBLOCKS) plane receiving the precipitation cover carried INTO each level
+  real_t* ckpt;  // CKPT + EVAP kernels only: (NPROMA,NLEV,NBLOCKS) plane receiving the precipitation cover carried INTO each
+                 // level.  Without the evaporation branch the carried cover feeds nothing but itself (level_forward stage G/J:
+                 // covpclr is only read under llo2; level_ad: its adjoint stays zero), so it is neither stored nor re-read.
 };
 struct TlArgs {
   Consts c; Geom g; Strides s, sp; InPtrs in; OutPtrs out; InPtrs din; OutPtrs dout; const LevelTab* tab;
@@ -316,8 +318,9 @@ C2_HD void satur_column(long long gcol, SaturArgsP a) {
 // ---------------------------------------------------------------------------------------------------------
 // NL: SATUR (optionally fused) + CLOUDSC2 for one column
 // ---------------------------------------------------------------------------------------------------------
-// CKPT: the sweep is the trajectory pass of the adjoint -- it additionally checkpoints the one carry that is not an
-// output (ZCOVPTOT5(JK-1)); rain and snow flux carries are the outputs PFPLSL5/PFPLSN5 themselves.
+// CKPT: the sweep is the trajectory pass of the adjoint.  Rain and snow flux carries are the outputs PFPLSL5/PFPLSN5
+// themselves; the one carry that is not an output (ZCOVPTOT5(JK-1)) is checkpointed -- only with the evaporation branch
+// (EVAP), the one place that reads it.
 template <unsigned F>
 C2_HD void nl_column(long long gcol, NlArgsP a) {
   constexpr bool HAS_QSAT = (F & C2F_QSAT) != 0, PERT = (F & C2F_PERT) != 0, P = (F & C2F_PRECISE) != 0, CKPT = (F & C2F_CKPT) != 0, EVAP = (F & C2F_EVAP) != 0;
@@ -349,8 +352,8 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
   ConstsP c = C2_CONSTS(a);
   InPtrsP in = &a->in;
   OutPtrsP out = &a->out;
-  real_t* ckpt = CKPT ? a->ckpt : nullptr;
-  const long long osc = CKPT ? (gcol / nproma) * ((long long)nproma * nlev) + (gcol % nproma) : 0;
+  real_t* ckpt = (CKPT && EVAP) ? a->ckpt : nullptr;
+  const long long osc = (CKPT && EVAP) ? (gcol / nproma) * ((long long)nproma * nlev) + (gcol % nproma) : 0;
 
   real_t ztrpaus = tropopause<PERT>(c, tab, in, o, &a->g, lam);
   RhCrit rh;
@@ -387,7 +390,7 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
     level_cst(tab, jk, last, k);
     LevelIn x;
     make_level_in(cur, paph_k, paph_surf, x);
-    if (CKPT) stg(ckpt, oscl + level_off(OT(), jk, nproma), cy.covptot);  // ZCOVPTOT5(JK-1)
+    if (CKPT && EVAP) stg(ckpt, oscl + level_off(OT(), jk, nproma), cy.covptot);  // ZCOVPTOT5(JK-1)
     LevelTraj tr;
     LevelOut lo;
 #ifdef C2_SKELETON  // diagnostic build only: the memory pattern of the sweep with the physics replaced by a few adds
@@ -499,9 +502,12 @@ C2_HD void tl_column(long long gcol, TlArgsP a) {
 
 // ---------------------------------------------------------------------------------------------------------
 // AD for one column.  Two passes: the trajectory pass is nl_column<.., CKPT=true> -- it writes the trajectory
-// outputs and checkpoints the three carries (rain and snow flux live in the outputs PFPLSL5/PFPLSN5 that have to be
-// written anyway, the precipitation cover goes to the scratch plane).  The reverse pass below re-evaluates each
-// level's trajectory from its checkpoint and applies the transposed level.
+// outputs and checkpoints the carries (rain and snow flux live in the outputs PFPLSL5/PFPLSN5 that have to be
+// written anyway; the precipitation cover goes to the scratch plane when the evaporation branch, its only reader, is
+// compiled in).  The reverse pass below re-evaluates each level's trajectory from its checkpoint and applies the
+// transposed level.  It needs nothing from the trajectory pass but PFPLSL5/PFPLSN5 (and the cover plane with EVAP), so a
+// caller that already has them -- any earlier NL or TL sweep over the same state -- can run it alone
+// (cloudsc2_ad_launch_reverse).
 // ---------------------------------------------------------------------------------------------------------
 
 // Everything the reverse pass reads for level jk: trajectory inputs, the three checkpointed carries, the output
@@ -516,7 +522,7 @@ struct AdLevelLoads {
   RawLevel xo;    // old input adjoints (PSUPSAT is assigned, not accumulated: not read)
 };
 
-template <bool HAS_QSAT, bool ASSIGN, class OT>
+template <bool HAS_QSAT, bool ASSIGN, bool EVAP, class OT>
 C2_HD void ad_load_level(AdArgsP ap, const LaneOffT<OT>& o, const LaneOffT<OT>& oa, OT osc, int nproma, int nlev, int jk,
                          AdLevelLoads& L) {
   const bool last = (jk == nlev - 1);
@@ -543,7 +549,8 @@ C2_HD void ad_load_level(AdArgsP ap, const LaneOffT<OT>& o, const LaneOffT<OT>& 
     const OutPtrs po = ap->nl.out;
     L.cy.rfl = ldg(po.fplsl, o.half + d);  // ZRFL5(JK) = PFPLSL5(JK)
     L.cy.sfl = ldg(po.fplsn, o.half + d);
-    L.cy.covptot = ldg(ap->nl.ckpt, osc + d);
+    // the carried cover matters to the evaporation branch alone; without it any value gives the same results (0 here)
+    L.cy.covptot = EVAP ? ldg(ap->nl.ckpt, osc + d) : RC(0.0);
   }
   const OutPtrs pa = ap->aout;
   L.ya.tent = ldg(pa.tent, oa.loc + d);
@@ -620,7 +627,7 @@ C2_HD void ad_reverse_column(long long gcol, AdArgsP a) {
     C2_LAUNDER(ap);
     // all 44 loads of the level at its top; requesting the trajectory part (19 values) one level ahead was measured: +1.6 % time
     // at 160 000 columns, -1 % at 1 M (profiles/r02_ab_experiments.txt)
-    ad_load_level<HAS_QSAT, ASSIGN>(ap, ol, oa, osc, nproma, nlev, jk, L);
+    ad_load_level<HAS_QSAT, ASSIGN, EVAP>(ap, ol, oa, osc, nproma, nlev, jk, L);
     RawLevel& cur = L.cur;
     cur.paph_k1 = paph_k1;
     const RawLevel& xo = L.xo;

@@ -218,9 +218,10 @@ template <class Args> using KernelFn = void (*)(Args);
   template <unsigned... F> constexpr std::array<KernelFn<Args>, sizeof...(F)> table##_make(                        \
       std::integer_sequence<unsigned, F...>) { return {{table##_entry<F>()...}}; }                                 \
   [[maybe_unused]] const std::array<KernelFn<Args>, NF> table = table##_make(std::make_integer_sequence<unsigned, NF>{});
-C2_VARIANT_TABLE(g_nl_kernels, nl_kernel, NlArgs, 64, !((F & C2F_PERT) && (F & C2F_CKPT)) && (C2_AD_FUSED == 1 ? !(F & C2F_CKPT) : true))
+// (the trajectory pass differs from the plain NL sweep only with the evaporation branch: the cover checkpoint)
+C2_VARIANT_TABLE(g_nl_kernels, nl_kernel, NlArgs, 64, !(F & C2F_CKPT) || ((F & C2F_EVAP) && !(F & C2F_PERT)))
 C2_VARIANT_TABLE(g_tl_kernels, tl_kernel, TlArgs, 64, !(F & 16u))
-C2_VARIANT_TABLE(g_ad_reverse_kernels, ad_reverse_kernel, AdArgs, 64, C2_AD_FUSED != 1 && !(F & 16u))
+C2_VARIANT_TABLE(g_ad_reverse_kernels, ad_reverse_kernel, AdArgs, 64, !(F & 16u))
 C2_VARIANT_TABLE(g_ad_kernels, ad_kernel, AdArgs, 64, C2_AD_FUSED != 0 && !(F & 16u))
 
 // ---------------------------------------------------------------------------------------------------------
@@ -630,32 +631,39 @@ int cloudsc2_tl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
   return launch_variant(g_tl_kernels[f], args, g.ncols_pad, (hipStream_t)stream);
 }
 
+// which == 0: both sweeps (fused kernel, or the two kernels in stream order); 1: forward sweep only; 2: reverse sweep only
 static int ad_launch_impl(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
                           const cloudsc2_inputs* traj_in, const cloudsc2_outputs* traj_out,
                           const cloudsc2_inputs* adj_in, const cloudsc2_outputs* adj_out, cloudsc2_real* scratch,
-                          void* stream, bool assign) {
+                          void* stream, bool assign, int which = 0) {
   Geom g;
   int rc = check_geom(prm, nproma, nlev, ngptot, g);
   if (rc) return rc;
-  if (!traj_in || !traj_out || !adj_in || !adj_out || !scratch) return fail(CLOUDSC2_EINVAL, "NULL argument block");
+  if (!traj_in || !traj_out || (which != 1 && (!adj_in || !adj_out))) return fail(CLOUDSC2_EINVAL, "NULL argument block");
   Strides s = {0, 0, 0, 0, 0}, sa = {0, 0, 0, 0, 0};
   InPtrs ip, aip_c; OutPtrs op, aop;
   if ((rc = resolve_in(*traj_in, false, s, ip))) return rc;
-  if ((rc = resolve_out(*traj_out, true, s, op))) return rc;
-  if ((rc = resolve_in(*adj_in, true, sa, aip_c))) return rc;
-  if ((rc = resolve_out(*adj_out, true, sa, aop))) return rc;
-  InPtrsRW aip;
-  aip.paph = adj_in->paph.ptr; aip.pap = adj_in->pap.ptr; aip.q = adj_in->q.ptr; aip.qsat = adj_in->qsat.ptr;
-  aip.t = adj_in->t.ptr; aip.l = adj_in->l.ptr; aip.i = adj_in->i.ptr; aip.lude = adj_in->lude.ptr;
-  aip.lu = adj_in->lu.ptr; aip.mfu = adj_in->mfu.ptr; aip.mfd = adj_in->mfd.ptr; aip.gt = adj_in->gtent.ptr;
-  aip.gq = adj_in->gtenq.ptr; aip.gl = adj_in->gtenl.ptr; aip.gi = adj_in->gteni.ptr; aip.supsat = adj_in->supsat.ptr;
+  // the reverse sweep alone reads PFPLSL5 / PFPLSN5 and nothing else of the trajectory outputs
+  if ((rc = resolve_out(*traj_out, which != 2, s, op))) return rc;
+  if (which == 2 && (!op.fplsl || !op.fplsn)) return fail(CLOUDSC2_EINVAL, "reverse sweep: traj_out->fplsl and ->fplsn (PFPLSL5, PFPLSN5) are required");
+  AdArgs args;
+  memset(&args, 0, sizeof(args));
+  if (which != 1) {
+    if ((rc = resolve_in(*adj_in, true, sa, aip_c))) return rc;
+    if ((rc = resolve_out(*adj_out, true, sa, aop))) return rc;
+    InPtrsRW aip;
+    aip.paph = adj_in->paph.ptr; aip.pap = adj_in->pap.ptr; aip.q = adj_in->q.ptr; aip.qsat = adj_in->qsat.ptr;
+    aip.t = adj_in->t.ptr; aip.l = adj_in->l.ptr; aip.i = adj_in->i.ptr; aip.lude = adj_in->lude.ptr;
+    aip.lu = adj_in->lu.ptr; aip.mfu = adj_in->mfu.ptr; aip.mfd = adj_in->mfd.ptr; aip.gt = adj_in->gtent.ptr;
+    aip.gq = adj_in->gtenq.ptr; aip.gl = adj_in->gtenl.ptr; aip.gi = adj_in->gteni.ptr; aip.supsat = adj_in->supsat.ptr;
+    args.sa = sa; args.ain = aip; args.aout = aop;
+  }
   const LevelTab* tab;
   if ((rc = get_tables(*prm, &tab, &g.kb0, &g.kb1))) return rc;
-  AdArgs args;
   args.nl.c = make_consts(*prm, ptsphy);
+  if (args.nl.c.evap && !scratch) return fail(CLOUDSC2_EINVAL, "LEVAPLS2/LDRAIN1D: the cover-checkpoint plane `scratch` is required");
   args.nl.g = g; args.nl.s = s; args.nl.in = ip; args.nl.out = op; args.nl.tab = tab;
   args.nl.zero_plane = nullptr; args.nl.zero_stride = 0; args.nl.lam = 0.0; args.nl.ckpt = scratch;
-  args.sa = sa; args.ain = aip; args.aout = aop;
   unsigned f = 0;
   if (traj_in->qsat.ptr) f |= C2F_QSAT;
   if (precise_of(prm)) f |= C2F_PRECISE;
@@ -663,10 +671,14 @@ static int ad_launch_impl(const cloudsc2_params* prm, double ptsphy, int nproma,
   if (assign) f |= C2F_ASSIGN;
   if (fits_off32(g, nproma, nlev, {s.full, s.half, s.cml, s.clv, s.loc, sa.full, sa.half, sa.cml, sa.clv, sa.loc,
                                   (long long)nproma * nlev /* scratch */})) f |= C2F_OFF32;
+  // the trajectory pass as a kernel of its own: the NL sweep, with the cover checkpoint when the evaporation branch is on
+  const unsigned f_fwd = (f & ~C2F_ASSIGN) | (args.nl.c.evap ? C2F_CKPT : 0u);
+  if (which == 1) return launch_variant(g_nl_kernels[f_fwd], args.nl, g.ncols_pad, (hipStream_t)stream);
+  if (which == 2) return launch_variant(g_ad_reverse_kernels[f], args, g.ncols_pad, (hipStream_t)stream);
   const bool fused = C2_AD_FUSED == 1 || (C2_AD_FUSED == 2 && g.ncols_pad > kAdSplitBelow);
   if (fused) return launch_variant(g_ad_kernels[f], args, g.ncols_pad, (hipStream_t)stream);
-  // trajectory pass (NL kernel + carry checkpoints), then the reverse pass, in stream order
-  if ((rc = launch_variant(g_nl_kernels[(f & ~C2F_ASSIGN) | C2F_CKPT], args.nl, g.ncols_pad, (hipStream_t)stream))) return rc;
+  // trajectory pass, then the reverse pass, in stream order
+  if ((rc = launch_variant(g_nl_kernels[f_fwd], args.nl, g.ncols_pad, (hipStream_t)stream))) return rc;
   return launch_variant(g_ad_reverse_kernels[f], args, g.ncols_pad, (hipStream_t)stream);
 }
 
@@ -682,6 +694,20 @@ int cloudsc2_ad_launch_assign(const cloudsc2_params* prm, double ptsphy, int npr
                               const cloudsc2_inputs* adj_in, const cloudsc2_outputs* adj_out, cloudsc2_real* scratch,
                               void* stream) {
   return ad_launch_impl(prm, ptsphy, nproma, nlev, ngptot, traj_in, traj_out, adj_in, adj_out, scratch, stream, true);
+}
+
+int cloudsc2_ad_launch_forward(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
+                               const cloudsc2_inputs* traj_in, const cloudsc2_outputs* traj_out, cloudsc2_real* scratch,
+                               void* stream) {
+  return ad_launch_impl(prm, ptsphy, nproma, nlev, ngptot, traj_in, traj_out, nullptr, nullptr, scratch, stream, false, 1);
+}
+
+int cloudsc2_ad_launch_reverse(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
+                               const cloudsc2_inputs* traj_in, const cloudsc2_outputs* traj_out,
+                               const cloudsc2_inputs* adj_in, const cloudsc2_outputs* adj_out, const cloudsc2_real* scratch,
+                               int assign, void* stream) {
+  return ad_launch_impl(prm, ptsphy, nproma, nlev, ngptot, traj_in, traj_out, adj_in, adj_out, const_cast<cloudsc2_real*>(scratch),
+                        stream, assign != 0, 2);
 }
 
 // ---------------------------------------------------------------------------------------------------------

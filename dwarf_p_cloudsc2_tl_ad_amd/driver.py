@@ -325,14 +325,26 @@ class DeviceState:
                                          C.byref(o), C.byref(di), C.byref(do), self._stream(stream)))
 
     def ad(self, prm: B.Params, adj_in: FlatFields, adj_out: FlatFields, scratch, stream=None, fused_satur: bool = False,
-           assign: bool = False):
-        """CLOUDSC2AD; assign=True: adj_in = A^T adj_out instead of adj_in += A^T adj_out (cloudsc2_ad_launch_assign)."""
+           assign: bool = False, sweep: str = "both"):
+        """CLOUDSC2AD; assign=True: adj_in = A^T adj_out instead of adj_in += A^T adj_out (cloudsc2_ad_launch_assign).
+        sweep = "forward" / "reverse": one of its two sweeps alone (cloudsc2_ad_launch_forward / _reverse; the reverse sweep takes
+        PFPLSL5 / PFPLSN5 from the state's flux arrays, where any earlier NL / TL / forward sweep left them).  `scratch` (the cover
+        checkpoints) may be None unless LEVAPLS2 / LDRAIN1D is on."""
         i = self.traj_inputs(not fused_satur)
         o = self.traj_outputs()
+        sc = C.c_void_p(scratch.data_ptr() if scratch is not None else None)
+        geom = (C.byref(prm), self.ptsphy, self.nproma, self.nlev, self.ngptot, C.byref(i), C.byref(o))
+        if sweep == "forward":
+            B.check(B.lib.cloudsc2_ad_launch_forward(*geom, sc, self._stream(stream)))
+            return
         ai, ao = adj_in.block(), adj_out.block()
-        B.check((B.lib.cloudsc2_ad_launch_assign if assign else B.lib.cloudsc2_ad_launch)(C.byref(prm), self.ptsphy, self.nproma, self.nlev, self.ngptot, C.byref(i),
-                                         C.byref(o), C.byref(ai), C.byref(ao), C.c_void_p(scratch.data_ptr()),
-                                         self._stream(stream)))
+        if sweep == "reverse":
+            B.check(B.lib.cloudsc2_ad_launch_reverse(*geom, C.byref(ai), C.byref(ao), sc, int(assign), self._stream(stream)))
+            return
+        if sweep != "both":
+            raise ValueError(sweep)
+        fn = B.lib.cloudsc2_ad_launch_assign if assign else B.lib.cloudsc2_ad_launch
+        B.check(fn(*geom, C.byref(ai), C.byref(ao), sc, self._stream(stream)))
 
     def increments(self, zero_supsat: bool = False, into: FlatFields | None = None) -> FlatFields:
         """dx = 0.01 * x for the 16 inputs (cloudsc_driver_tl_mod.F90:156-171); ZSUPSAT = 0 in the adjoint test

@@ -239,9 +239,15 @@ def _reals_per_column(nlev: int, kernel: str) -> int:
         return nl_in + nl_out + full
     if kernel == "tl":
         return nl_in + full + (half + 15 * full) + 2 * nl_out
-    if kernel == "ad":
-        x = half + 15 * full
+    x = half + 15 * full
+    if kernel == "ad":                        # traj in (+PQS5), y in, x in (+=), y <- 0, x out, traj out
         return (nl_in + full) + nl_out + x + nl_out + x + nl_out
+    if kernel == "ad_reverse":                # reverse sweep alone: traj in (+PQS5), PFPLSL5/PFPLSN5 at JK, y in, x in, y <- 0, x out
+        return (nl_in + full) + 2 * full + nl_out + x + nl_out + x
+    if kernel == "ad_ckpt":                   # the cover-checkpoint plane, written and re-read (evaporation branch only)
+        return 2 * full
+    if kernel == "ad_old_adjoints":           # the 16 old input adjoints, which the assign forms do not read
+        return x
     raise ValueError(kernel)
 
 

@@ -162,8 +162,9 @@ int cloudsc2_tl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
 /* CLOUDSC2AD (src/cloudsc2_ad/cloudsc2ad.F90:10-24): trajectory in -> trajectory out; adj_out holds the
  * output adjoints on entry and is zeroed on return (:917-919,955-966,1173,1572,1678-1691); adj_in is
  * accumulated (+=, :1723-1738) except PSUPSAT which is assigned PTSPHY*zqp1 exactly as the reference does
- * (:1733).  `scratch` must hold (ngptot rounded up to NPROMA blocks) * nlev elements (precipitation-cover
- * carry checkpoints). */
+ * (:1733).  `scratch` must hold (ngptot rounded up to NPROMA blocks) * nlev elements: the precipitation-cover
+ * carry checkpoints, written and re-read only when LEVAPLS2 .OR. LDRAIN1D (the evaporation branch is the carried
+ * cover's one reader); otherwise it is not touched and may be NULL. */
 int cloudsc2_ad_launch(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
                        const cloudsc2_inputs* traj_in, const cloudsc2_outputs* traj_out,
                        const cloudsc2_inputs* adj_in, const cloudsc2_outputs* adj_out,
@@ -177,6 +178,22 @@ int cloudsc2_ad_launch_assign(const cloudsc2_params* prm, double ptsphy, int npr
                               const cloudsc2_inputs* traj_in, const cloudsc2_outputs* traj_out,
                               const cloudsc2_inputs* adj_in, const cloudsc2_outputs* adj_out,
                               cloudsc2_real* scratch, void* stream);
+
+/* CLOUDSC2AD as its two sweeps.  _forward is the forward sweep (cloudsc2ad.F90:366-866): trajectory in -> trajectory out
+ * (+ the cover checkpoints in `scratch` when LEVAPLS2 .OR. LDRAIN1D).  _reverse is the reverse sweep (:877-1740): it re-reads
+ * the trajectory inputs, takes the rain / snow flux carried into every level from traj_out->fplsl / fplsn (PFPLSL5, PFPLSN5;
+ * the other traj_out fields are not read and may be NULL) and, with the evaporation branch only, the cover from `scratch`;
+ * adj_out / adj_in as for cloudsc2_ad_launch (assign != 0: as for cloudsc2_ad_launch_assign).  _forward + _reverse on one
+ * stream equals cloudsc2_ad_launch bit for bit.  A caller whose PFPLSL5 / PFPLSN5 are already on the device -- any NL or TL
+ * sweep over the same state wrote them, e.g. the TL leg of the adjoint test (cloudsc_driver_ad_mod.F90:160-181) -- runs
+ * _reverse alone and saves the trajectory pass (28.5 KB per column of traffic). */
+int cloudsc2_ad_launch_forward(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
+                               const cloudsc2_inputs* traj_in, const cloudsc2_outputs* traj_out,
+                               cloudsc2_real* scratch, void* stream);
+int cloudsc2_ad_launch_reverse(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
+                               const cloudsc2_inputs* traj_in, const cloudsc2_outputs* traj_out,
+                               const cloudsc2_inputs* adj_in, const cloudsc2_outputs* adj_out,
+                               const cloudsc2_real* scratch, int assign, void* stream);
 
 /* Taylor-test statistics for one lambda (ERROR_NORM, cloudsc_driver_tl_mod.F90:21-31, calls :233-244):
  * for each NPROMA block and each of the 10 output fields, sums over the block's active columns and all

@@ -31,11 +31,12 @@ template <unsigned F> struct HcTl {
     if constexpr ((F & ~(C2F_QSAT | C2F_PRECISE | C2F_EVAP | C2F_TRAJ | C2F_OFF32)) == 0) tl_column<F>(gc, a);
   }
 };
+static int g_hc_ad_sweep = 0;  // 0: both sweeps of the adjoint, 1: forward sweep only, 2: reverse sweep only
 template <unsigned F> struct HcAd {
   static void run(long long gc, const AdArgs* a) {
     if constexpr ((F & ~(C2F_QSAT | C2F_PRECISE | C2F_EVAP | C2F_OFF32 | C2F_ASSIGN)) == 0) {
-      nl_column<(F & ~C2F_ASSIGN) | C2F_CKPT>(gc, &a->nl);
-      ad_reverse_column<F>(gc, a);
+      if (g_hc_ad_sweep != 2) nl_column<(F & ~C2F_ASSIGN) | C2F_CKPT>(gc, &a->nl);
+      if (g_hc_ad_sweep != 1) ad_reverse_column<F>(gc, a);
     }
   }
 };
@@ -84,6 +85,7 @@ extern "C" {
 
 void hostcheck_set_precise(int p) { g_hc_precise = p; }
 void hostcheck_set_assign(int v) { g_hc_assign = v; }  // AD: assign the input adjoints instead of accumulating (C2F_ASSIGN)
+void hostcheck_set_ad_sweep(int v) { g_hc_ad_sweep = v; }  // what cloudsc2_ad_launch_forward / _reverse run
 void hostcheck_set_off32(int v) { g_hc_off32 = v; }  // 32-bit byte offsets (C2F_OFF32) in all three sweeps
 
 int hostcheck_satur(const cloudsc2_params* prm, int nproma, int nlev, int ngptot, cloudsc2_field pap, cloudsc2_field t,

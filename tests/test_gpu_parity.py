@@ -202,6 +202,60 @@ def test_tl_ad_kernels_match_checker(flags, nproma, ngptot):
     # (PSUPSAT excluded: the reference assigns its adjoint with a spurious PTSPHY factor, cloudsc2ad.F90:1733)
 
 
+@pytest.mark.parametrize("flags", [dict(lregcl=True), dict(levapls2=True, lregcl=True)])
+@pytest.mark.parametrize("assign", [False, True])
+def test_adjoint_as_two_sweeps_equals_the_whole(flags, assign):
+    """cloudsc2_ad_launch_forward + cloudsc2_ad_launch_reverse = cloudsc2_ad_launch bit for bit (CLOUDSC2AD is its forward sweep,
+    cloudsc2ad.F90:366-866, followed by its reverse sweep, :877-1740); the reverse sweep ALONE after a TL launch that stored the
+    trajectory outputs gives the same again (what cloudsc2_ad_symmetry_run does); and without the evaporation branch the
+    cover-checkpoint plane is not needed at all (NULL) -- with it, a missing plane is refused."""
+    import torch
+
+    tab = c2.random_table(137, 100, seed=11) if flags.get("levapls2") else c2.synthetic_table()
+    nproma, ngptot = 64, 300
+    prm = c2.default_params(c2.ceta_from_table(tab), **flags)
+    st = c2.state_from_table(tab, nproma, ngptot)
+    evap = bool(flags.get("levapls2"))
+
+    def run(mode):
+        ds = c2.DeviceState(st, "cuda:0")
+        ds.satur(prm)
+        inc = ds.increments(zero_supsat=True)
+        y = c2.FlatFields("out", ds.nb, ds.nlev, nproma, ds.device)
+        ds.tl(prm, inc, y)  # trajectory outputs stored: PFPLSL5 / PFPLSN5 are in the state afterwards
+        x = c2.FlatFields("in", ds.nb, ds.nlev, nproma, ds.device)
+        for t in x.t.values():
+            t.fill_(0.5)
+        scratch = ds.new_scratch() if (evap or mode == "whole") else None
+        if mode == "whole":
+            ds.ad(prm, x, y, scratch, assign=assign)
+        elif mode == "two":
+            ds.ad(prm, x, y, scratch, sweep="forward")
+            ds.ad(prm, x, y, scratch, assign=assign, sweep="reverse")
+        else:  # reverse sweep alone on what the TL launch left (with the evaporation branch the checkpoints must exist)
+            if evap:
+                ds.ad(prm, x, y, scratch, sweep="forward")
+                for n in ("B_LOC", "PA", "PCOVPTOT", "PFHPSL", "PFHPSN"):
+                    getattr(ds, n).fill_(float("nan"))  # nothing of the trajectory outputs but the two flux carries is read
+            ds.ad(prm, x, y, scratch, assign=assign, sweep="reverse")
+        torch.cuda.synchronize()
+        return {n: t.cpu().numpy() for n, t in x.t.items()}, {n: t.cpu().numpy() for n, t in y.t.items()}
+
+    xw, yw = run("whole")
+    for mode in ("two", "reverse"):
+        xm, ym = run(mode)
+        for n in xw:
+            assert np.array_equal(xw[n], xm[n]), (mode, n)
+        for n in yw:
+            assert np.array_equal(yw[n], ym[n]), (mode, n)
+    if evap:
+        ds = c2.DeviceState(st, "cuda:0")
+        x = c2.FlatFields("in", ds.nb, ds.nlev, nproma, ds.device)
+        y = c2.FlatFields("out", ds.nb, ds.nlev, nproma, ds.device)
+        with pytest.raises(RuntimeError, match="checkpoint"):
+            ds.ad(prm, x, y, None, sweep="reverse")
+
+
 @pytest.mark.parametrize("nlev", [11, 60, 200])
 def test_other_numbers_of_levels(nlev):
     """NLEV other than 137 (the kernels take it at run time; CETA holds up to 200 levels): NL through the driver, TL and

@@ -153,6 +153,32 @@ def test_tl_ad_columns(oracle, flags, nlev):
         for n in y4:
             assert np.all(y4[n][ibl][:, :icend] == 0.0), ("assign: output adjoint not consumed", n)
 
+    # The reverse sweep alone (cloudsc2_ad_launch_reverse) on the trajectory outputs the TL sweep left behind equals the whole
+    # adjoint bit for bit; it reads nothing of the trajectory outputs but PFPLSL5 / PFPLSN5 (everything else is poisoned here) and,
+    # without the evaporation branch, neither sweep touches the cover-checkpoint plane (NaN-filled: a read would poison x).
+    evap = bool(flags.get("levapls2", False) or flags.get("ldrain1d", False))
+    hc.hostcheck_set_ad_sweep(2)
+    try:
+        got5 = got.copy()  # the state after hostcheck_tl: trajectory outputs included
+        for n in ("B_LOC", "PA", "PCOVPTOT", "PFHPSL", "PFHPSN"):
+            getattr(got5, n)[...] = np.nan
+        i5, o5_ = host_traj_blocks(got5, qsat)
+        x5 = flat_fields("in", nb, nlev, nproma)
+        y5 = {n: a.copy() for n, a in tl.items()}
+        ck5 = scratch.copy() if evap else np.full((nb, nlev, nproma), np.nan)
+        ai5, ao5 = flat_block("in", x5), flat_block("out", y5)
+        assert hc.hostcheck_ad(C.byref(prm), st.ptsphy, nproma, nlev, ngptot, C.byref(i5), C.byref(o5_), C.byref(ai5), C.byref(ao5),
+                               ck5.ctypes.data) == 0
+    finally:
+        hc.hostcheck_set_ad_sweep(0)
+    for n in x:
+        assert np.array_equal(x[n], x5[n]), ("reverse sweep alone", n)
+    for n in y5:
+        assert np.array_equal(y[n], y5[n]), ("reverse sweep alone: output adjoints", n)
+    if not evap:
+        assert np.all(scratch == 0.0), "the forward sweep wrote cover checkpoints nobody reads"
+        assert np.all(np.isnan(ck5))
+
     ld = bool(flags.get("ldrain1d", False))
     for ibl in range(nb):
         icend = min(nproma, ngptot - ibl * nproma)
