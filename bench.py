@@ -37,8 +37,10 @@ def select_pmc_traffic(pdir, kernel, ngptot, real_bytes, algorithmic_bytes):
     """HBM traffic of one launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*pmc_traffic.json, written by
     tools/pmc_parse.py).  The pass is chosen by its CONTENT -- `real_bytes` (precision), `ngptot` (launch size), the kernel's
     entry and the algorithmic bytes it was taken with (a pass of an older form of the kernel is stale) -- never by its file
-    name; the newest round's file wins among equals.  A figure below the algorithmic bytes is impossible for this path (every
-    plane element is moved at least once) and is rejected.  Returns (bytes or None, dict of fields for the line)."""
+    name; the newest round's file wins among equals.  A figure far below the algorithmic bytes is impossible for this path and
+    is rejected (the fp32 library's pass on an fp64 line would read 0.5; the reverse sweep of the adjoint alone legitimately
+    reads 0.96: the compiler drops the loads of two adjoint planes that only feed the compiled-out evaporation branch, which
+    SURVEY's per-plane count includes).  Returns (bytes or None, dict of fields for the line)."""
     cands = []
     for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
         if not f.endswith("pmc_traffic.json"):
@@ -60,7 +62,7 @@ def select_pmc_traffic(pdir, kernel, ngptot, real_bytes, algorithmic_bytes):
     same, fname, traffic = cands[-1]
     info = {"traffic_source": f"profiles/{fname} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run, "
                               f"{'same' if same else 'another'} launch size, scaled per column; not measured in this run)"}
-    if traffic < 0.999 * algorithmic_bytes:
+    if traffic < 0.9 * algorithmic_bytes:
         info["traffic_rejected"] = f"{traffic:.4g} B is below the algorithmic {algorithmic_bytes:.4g} B"
         return None, info
     return traffic, info

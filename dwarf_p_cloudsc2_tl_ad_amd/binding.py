@@ -188,7 +188,7 @@ def _load() -> C.CDLL:
 lib = _load()
 
 # every symbol include/cloudsc2_hip.h declares
-EXPORTED = ("cloudsc2_params_default", "cloudsc2_last_error", "cloudsc2_device_available", "cloudsc2_set_math_mode",
+EXPORTED = ("cloudsc2_params_default", "cloudsc2_last_error", "cloudsc2_device_available", "cloudsc2_current_device", "cloudsc2_set_math_mode",
             "cloudsc2_get_math_mode", "cloudsc2_real_bytes", "cloudsc2_nl_launch",
             "cloudsc2_satur_launch", "cloudsc2_tl_launch", "cloudsc2_ad_launch", "cloudsc2_ad_launch_assign",
             "cloudsc2_ad_launch_forward", "cloudsc2_ad_launch_reverse", "cloudsc2_taylor_sums_launch",

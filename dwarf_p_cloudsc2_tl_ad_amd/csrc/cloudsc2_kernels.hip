@@ -230,8 +230,10 @@ C2_VARIANT_TABLE(g_ad_kernels, ad_kernel, AdArgs, 64, C2_AD_FUSED != 0 && !(F & 
 // the outputs with a KLON-column reference (validate_mod.F90:165-261).  Both work from the small table on the
 // device, so a 1M-column state never exists on the host and the reference is never expanded at all.
 // ---------------------------------------------------------------------------------------------------------
-// field(jl, jk, jm, ibl) = table((start + ibl*NPROMA + jl) mod period, jk, jm) for active columns, 0 for the padded
-// tail of the last block (expand_mod.F90:283-296; `start`,`period` = get_offsets, :30-46).
+// field(jl, jk, jm, ibl) = table((start + (ibl*NPROMA + jl) mod period) mod KLON, jk, jm) for active columns, 0 for the
+// padded tail of the last block: the rank's table slice START..END (get_offsets, expand_mod.F90:30-46) tiled with period
+// SIZE (load_and_expand + expand_r2, :101-116,283-296).  The outer mod KLON never acts for those pairs (start + period <= KLON);
+// it lets period = KLON with any start >= 0 express "the periodic tiling continues at global column `start`".
 __global__ void __launch_bounds__(256)
 expand_kernel(const real_t* __restrict__ table, int klon, int period, long long start, int nlevx, int ndim, int nproma,
               long long ngptot, long long nblocks, real_t* __restrict__ field, long long block_stride) {
@@ -244,7 +246,7 @@ expand_kernel(const real_t* __restrict__ table, int klon, int period, long long 
     const long long lev = r / nproma;  // jk + nlevx*jm
     const long long g = ibl * nproma + jl;
     real_t v = 0;
-    if (g < ngptot) v = table[(start + g) % period + (long long)klon * lev];
+    if (g < ngptot) v = table[(start + g % period) % klon + (long long)klon * lev];
     field[ibl * block_stride + r] = v;
   }
 }
@@ -269,7 +271,7 @@ validate_partial_kernel(const real_t* __restrict__ table, int klon, int period, 
     vmin = fmin(vmin, f);
     vmax = fmax(vmax, f);
     if (g < ngptot) {
-      const double ref = table[(start + g) % period + (long long)klon * lev];
+      const double ref = table[(start + g % period) % klon + (long long)klon * lev];
       const double d = fabs(f - ref);
       emax = fmax(emax, d);
       esum += d;
@@ -505,6 +507,11 @@ extern "C" {
 const char* cloudsc2_last_error(void) { return g_err.c_str(); }
 
 int cloudsc2_device_available(void) { return device_ok() ? 1 : 0; }
+int cloudsc2_current_device(void) {
+  int dev = 0;
+  if (!device_ok() || hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return dev;
+}
 int cloudsc2_real_bytes(void) { return (int)sizeof(cloudsc2_real); }
 
 void cloudsc2_set_math_mode(int precise) { g_precise.store(precise ? 1 : 0); }

@@ -65,6 +65,9 @@ void cloudsc2_params_default(cloudsc2_params* p);
 const char* cloudsc2_last_error(void);
 /* 1 if a HIP device is usable by this process, else 0. */
 int cloudsc2_device_available(void);
+/* ordinal of the calling thread's current HIP device (what the Fortran timing table prints where the reference's prints the
+ * core a thread ran on, timer_mod.F90:97,159-162); 0 when there is no device */
+int cloudsc2_current_device(void);
 /* sizeof(cloudsc2_real) of THIS build of the library: 8, or 4 for the -DCLOUDSC2_SINGLE build. */
 int cloudsc2_real_bytes(void);
 
@@ -309,9 +312,12 @@ int cloudsc2_adjoint_verdict(double znormg);
  * reader/writer itself is include/cloudsc2_io.h (libcloudsc2_io.so, needs libhdf5).
  *
  * cloudsc2_expand_launch  replaces EXPAND_R2/R3 (src/common/module/expand_mod.F90:270-335) for data that
- *   stays on the GPU: field(jl,jk,jm,ibl) = table((start + ibl*NPROMA + jl) mod period, jk, jm), zero in the
- *   padded tail of the last block.  `table` (device) is (KLON, nlevx, ndim) column-fastest; `period` and
- *   `start` are GET_OFFSETS' size and start-1 (expand_mod.F90:30-46; see cloudsc2_expand_offsets).  The
+ *   stays on the GPU: field(jl,jk,jm,ibl) = table((start + (ibl*NPROMA + jl) mod period) mod KLON, jk, jm), zero in
+ *   the padded tail of the last block.  `table` (device) is (KLON, nlevx, ndim) column-fastest; `period` and
+ *   `start` are GET_OFFSETS' size and start-1 (expand_mod.F90:30-46; see cloudsc2_expand_offsets): the rank's
+ *   table slice START..END tiled with period SIZE, as LOAD_AND_EXPAND does (:101-116).  (For those pairs start + period
+ *   <= KLON and the outer mod never acts; with period = KLON any start >= 0 continues the periodic tiling at global
+ *   column `start`.)  The
  *   reference indexes out of bounds when a block starts at a multiple of KLON other than KLON itself
  *   (MOD(gidx,nlon) = 0, :289); this implements the periodic tiling it intends.
  * cloudsc2_validate_launch  replaces VALIDATE_R2/R3 (src/common/module/validate_mod.F90:165-261) without

@@ -160,6 +160,89 @@ class RefLib(_KernelLib):
         big_stack(self.lib.ref_driver, which, numomp, nproma, nlev, ngptot, float(ptsphy), *[self._a(a) for a in arrays18])
 
 
+    # ---- the data formats either side of the path, straight from the reference's modules ----
+    @staticmethod
+    def _capture(fd: int, fn, *args):
+        """Run fn(*args) with file descriptor fd (1 = Fortran unit 6, 2 = unit 0) redirected to a file; return what was written."""
+        import tempfile
+
+        with tempfile.TemporaryFile() as tmp:
+            saved = os.dup(fd)
+            try:
+                os.dup2(tmp.fileno(), fd)
+                fn(*args)
+            finally:
+                os.dup2(saved, fd)
+                os.close(saved)
+            tmp.seek(0)
+            return tmp.read().decode()
+
+    def get_offsets(self, irank: int, numproc: int, nlon: int, ngptot: int, ngptotg: int | None):
+        """GET_OFFSETS (expand_mod.F90:30-46): (start, end, size), 1-based like the reference."""
+        st, en, sz = C.c_int(), C.c_int(), C.c_int()
+        self.lib.ref_get_offsets.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_int)] * 3
+        self.lib.ref_get_offsets.restype = None
+        self.lib.ref_get_offsets(irank, numproc, nlon, ngptot, -1 if ngptotg is None else ngptotg, C.byref(st), C.byref(en), C.byref(sz))
+        return st.value, en.value, sz.value
+
+    def expand(self, buffer: np.ndarray, nproma: int, ngptot: int) -> np.ndarray:
+        """EXPAND_R2 / EXPAND_R3 (expand_mod.F90:270-335).  buffer: (NLEV, NLON) or (NDIM, NLEV, NLON) doubles = Fortran
+        (NLON, NLEV[, NDIM]); returns (NBLOCKS, [NDIM,] NLEV, NPROMA) = Fortran (NPROMA, NLEV, [NDIM,] NBLOCKS)."""
+        buf = np.ascontiguousarray(buffer, dtype=np.float64)
+        nblocks = (ngptot + nproma - 1) // nproma
+        nlon = buf.shape[-1]
+        if buf.ndim == 2:
+            field = np.full((nblocks, buf.shape[0], nproma), np.nan, dtype=self.dtype)
+            self.lib.ref_expand_r2.argtypes = [C.c_void_p] * 2 + [C.c_int] * 5
+            self.lib.ref_expand_r2.restype = None
+            self.lib.ref_expand_r2(_p(buf), self._a(field), nlon, nproma, buf.shape[0], ngptot, nblocks)
+        else:
+            field = np.full((nblocks, buf.shape[0], buf.shape[1], nproma), np.nan, dtype=self.dtype)
+            self.lib.ref_expand_r3.argtypes = [C.c_void_p] * 2 + [C.c_int] * 6
+            self.lib.ref_expand_r3.restype = None
+            self.lib.ref_expand_r3(_p(buf), self._a(field), nlon, nproma, buf.shape[1], buf.shape[0], ngptot, nblocks)
+        return field
+
+    def validate(self, name: str, ref: np.ndarray, field: np.ndarray, ngptot: int, ngptotg: int | None = None) -> str:
+        """VALIDATE_R2 / VALIDATE_R3 (validate_mod.F90:165-261) on blocked arrays (NBLOCKS, [NDIM,] NLEV, NPROMA): the line
+        ERROR_PRINT writes (validate_mod.F90:263-296), without the newline."""
+        r = np.ascontiguousarray(ref, dtype=self.dtype)
+        f = np.ascontiguousarray(field, dtype=self.dtype)
+        assert r.shape == f.shape
+        nm = name.encode()
+        g = -1 if ngptotg is None else ngptotg
+        if r.ndim == 3:
+            nb, nlev, nproma = r.shape
+            self.lib.ref_validate_r2.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p] + [C.c_int] * 5
+            self.lib.ref_validate_r2.restype = None
+            out = self._capture(1, self.lib.ref_validate_r2, nm, len(nm), self._a(r), self._a(f), nproma, nlev, ngptot, nb, g)
+        else:
+            nb, ndim, nlev, nproma = r.shape
+            self.lib.ref_validate_r3.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p] + [C.c_int] * 6
+            self.lib.ref_validate_r3.restype = None
+            out = self._capture(1, self.lib.ref_validate_r3, nm, len(nm), self._a(r), self._a(f), nproma, nlev, ndim, ngptot, nb, g)
+        return out.rstrip("\n")
+
+    def error_print(self, name: str, zminval, zmaxval, zmaxerr, zerrsum, zsum, zavgpgp, ndim: int) -> str:
+        """ERROR_PRINT (validate_mod.F90:263-296) for given statistics."""
+        nm = name.encode()
+        self.lib.ref_error_print.argtypes = [C.c_char_p, C.c_int] + [C.c_double] * 6 + [C.c_int]
+        self.lib.ref_error_print.restype = None
+        return self._capture(1, self.lib.ref_error_print, nm, len(nm), float(zminval), float(zmaxval), float(zmaxerr), float(zerrsum),
+                             float(zsum), float(zavgpgp), ndim).rstrip("\n")
+
+    def timer_print(self, nproma: int, ngpblks: int, ngptot: int, tthread, coreid, icalls, igpc, tdiff: float,
+                    zhpm: float = 3996006.0) -> str:
+        """PERFORMANCE_TIMER%PRINT_PERFORMANCE (timer_mod.F90:114-174) for given per-thread seconds / core ids / calls / columns
+        and region seconds: the table it writes on unit 0."""
+        tt = np.ascontiguousarray(tthread, dtype=np.float64)
+        ints = [np.ascontiguousarray(a, dtype=np.int32) for a in (coreid, icalls, igpc)]
+        self.lib.ref_timer_print.argtypes = [C.c_int] * 4 + [C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]
+        self.lib.ref_timer_print.restype = None
+        return self._capture(2, self.lib.ref_timer_print, int(tt.size), nproma, ngpblks, ngptot, float(zhpm), _p(tt),
+                             *[_p(a, np.int32) for a in ints], float(tdiff))
+
+
 class OracleLib(_KernelLib):
     prefix = "oracle_"
 

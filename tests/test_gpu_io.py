@@ -6,7 +6,7 @@ from __future__ import annotations
 import numpy as np
 import pytest
 
-from tests.util import B, c2
+from tests.util import B, c2, refcall
 from dwarf_p_cloudsc2_tl_ad_amd import fileio
 
 pytestmark = pytest.mark.gpu
@@ -16,7 +16,7 @@ def host_validate(field, ref_tab, nproma, ngptot, start=0, period=None):
     """VALIDATE_R2 / R3 in numpy: field (NBLOCKS, [NDIM,] NLEVx, NPROMA), ref_tab ([NDIM,] NLEVx, KLON)."""
     klon = ref_tab.shape[-1]
     period = klon if period is None else period
-    cols = (start + np.arange(ngptot)) % period
+    cols = (start + np.arange(ngptot) % period) % klon
     nlevx = field.shape[-2]
     if field.ndim == 3:
         f = field.transpose(0, 2, 1).reshape(-1, nlevx)[:ngptot]           # (col, lev)
@@ -46,8 +46,69 @@ def test_device_expand_equals_host_tiling(nproma, ngptot, start, period):
     else:
         # a rank whose table slice is shorter than KLON (GET_OFFSETS: size = min(nlon, ngptot), start = rank offset)
         cols = ds.PT.cpu().numpy().transpose(0, 2, 1).reshape(-1, 137)
-        idx = (start + np.arange(ngptot)) % period
+        idx = (start + np.arange(ngptot) % period) % 100  # GET_OFFSETS' slice START..END tiled with period SIZE
         assert np.array_equal(cols[:ngptot], tab["PT"].T[idx]) and not cols[ngptot:].any()
+
+
+def _fortran_real(tok: str) -> float:
+    """E20.13 output back to a number ('0.1000000000000-299' has no E)."""
+    import re
+
+    return float(re.sub(r"(?<=\d)([+-]\d{3})$", r"E\1", tok))
+
+
+@pytest.mark.skipif(not refcall.have_ref(), reason="oracle/_ref/libcloudsc2_ref.so did not travel")
+@pytest.mark.parametrize("nproma,ngptot,split", [(32, 250, None), (128, 1000, None), (64, 70, None), (16, 25, (100, 2, 4)), (2, 13, (50, 1, 4))])
+def test_device_tiler_and_validator_against_the_reference_modules(nproma, ngptot, split):
+    """The device tiler = EXPAND_R2 / EXPAND_R3 of the reference's expand_mod (bit for bit, also for a rank of a multi-rank run:
+    GET_OFFSETS + LOAD_AND_EXPAND), and the device validator's report = VALIDATE_R2 / R3 + ERROR_PRINT of validate_mod run on
+    the host arrays: minimum, maximum and largest error equal in every printed digit, the two sums (whose order of addition
+    differs) to 1e-12.  The modules are compiled unmodified into oracle/_ref (oracle/Makefile)."""
+    import torch
+
+    reflib = refcall.RefLib()
+    tab = c2.random_table(137, 100, seed=13)
+    start, period, ngptotg = 0, None, None
+    if split is not None:  # rank `irank` of `numproc`, table covering the global domain (rank offsets apply)
+        ngptotg, irank, numproc = split
+        s1, e1, size = reflib.get_offsets(irank, numproc, 100, ngptot, ngptotg)
+        start, period = B.expand_offsets(100, ngptot, ngptotg, irank, numproc)
+        assert (start, period) == (s1 - 1, size)
+    ds = c2.DeviceState.from_table(tab, nproma, ngptot, start=start, period=period)
+    torch.cuda.synchronize()
+    sl = slice(start, start + (100 if period is None else period))  # the columns LOAD_ARRAY hands to EXPAND
+    for name in ("PT", "PQ", "PAP", "PAPH", "PLU", "PLUDE", "PMFU", "PMFD", "PA", "PSUPSAT"):
+        assert np.array_equal(getattr(ds, name).cpu().numpy(), reflib.expand(tab[name][:, sl], nproma, ngptot)), name
+    zero = np.zeros_like(tab["PT"])
+    pclv = np.stack([tab["PCLV_QL"], tab["PCLV_QI"], zero, zero, zero])
+    assert np.array_equal(ds.PCLV.cpu().numpy(), reflib.expand(pclv[:, :, sl], nproma, ngptot))
+
+    # something to validate: NL outputs, against a reference table that differs from them in the 9th digit
+    prm = c2.default_params(c2.ceta_from_table(tab))
+    ds.nl(prm)
+    torch.cuda.synchronize()
+    st = ds.download(c2.state_from_table(tab, nproma, ngptot))
+    cols = (start + np.arange(min(100, ngptot)) % (100 if period is None else period)) % 100
+    rng = np.random.default_rng(3)
+    fields = {"PLUDE": st.PLUDE, "PCOVPTOT": st.PCOVPTOT, "PFPLSL": st.PFPLSL, "PFPLSN": st.PFPLSN, "PFHPSL": st.PFHPSL,
+              "PFHPSN": st.PFHPSN, "TENDENCY_LOC_A": st.B_LOC[:, 1], "TENDENCY_LOC_Q": st.B_LOC[:, 2],
+              "TENDENCY_LOC_T": st.B_LOC[:, 0], "TENDENCY_LOC_CLD": st.B_LOC[:, 3:8]}
+    ref_tab = {}
+    for name, f in fields.items():  # a KLON-column table whose tiling is the field, perturbed
+        per_col = f.transpose(0, 2, 1).reshape(-1, f.shape[-2]).T[:, :ngptot] if f.ndim == 3 else \
+            f.transpose(1, 2, 0, 3).reshape(f.shape[1], f.shape[2], -1)[:, :, :ngptot]
+        t = np.zeros(per_col.shape[:-1] + (100,))
+        t[..., cols] = per_col[..., : len(cols)]
+        ref_tab[name] = t * (1.0 + 1e-9 * rng.standard_normal(t.shape))
+    rows, text = ds.validate(ref_tab, ngptotg=ngptotg, start=start, period=period)
+    lines = text.split("\n")[1:]
+    for (label, ndim, stats), line, (name, f) in zip(rows, lines, fields.items()):
+        blocked_ref = reflib.expand(ref_tab[name][..., sl], nproma, ngptot)
+        want = reflib.validate(label, blocked_ref, f, ngptot, ngptotg)
+        assert line[:88] == want[:88], (label, line, want)  # name, nD-option, MinValue, MaxValue, AbsMaxErr
+        for a, b in ((line[88:109], want[88:109]), (line[109:130], want[109:130])):
+            assert abs(_fortran_real(a.strip()) - _fortran_real(b.strip())) <= 1e-12 * abs(_fortran_real(b.strip())), (label, a, b)
+        assert line[130:] == want[130:], (label, line, want)  # the `!!!!` flag
 
 
 def test_expand_and_validate_reject_bad_arguments():
