@@ -206,6 +206,9 @@ C2_HD void make_level_in(const RawLevel& cur, real_t paph_k, real_t paph_surf, L
 #ifndef C2_TROP_BATCH
 #define C2_TROP_BATCH 16
 #endif
+#ifndef C2_TROP_DEFER
+#define C2_TROP_DEFER 0
+#endif
 template <bool PERT>
 C2_HD real_t tropopause(ConstsP c, LevelTabP tab, InPtrsP p, const LaneOff& o, GeomP g, real_t lam) {
   real_t ztrpaus = RC(0.1);
@@ -355,9 +358,19 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
   real_t* ckpt = (CKPT && EVAP) ? a->ckpt : nullptr;
   const long long osc = (CKPT && EVAP) ? (gcol / nproma) * ((long long)nproma * nlev) + (gcol % nproma) : 0;
 
+  // ZTRPAUS (cloudsc2.F90:315-326) is only read by levels with CETA >= ZETA3 >= 0.1 (:391-399: above that ZCRH2 = 1 whatever it
+  // is), i.e. from the first band level kb0 on.  C2_TROP_DEFER: the band's pre-scan runs when the sweep reaches kb0 instead of
+  // before level 1 -- the waves of a launch then do it at different moments instead of all at once at the start, and the main
+  // sweep re-reads the band's rows soon after the pre-scan fetched them.
+#if C2_TROP_DEFER
+  const int ktrop = a->g.kb1 > a->g.kb0 ? a->g.kb0 : 0;
+  RhCrit rh;
+  rhcrit_setup(RC(1.0), rh);  // placeholder: every level before kb0 has CETA <= 0.1 < ZETA3
+#else
   real_t ztrpaus = tropopause<PERT>(c, tab, in, o, &a->g, lam);
   RhCrit rh;
   rhcrit_setup(ztrpaus, rh);
+#endif
 
   real_t paph_surf = RC(0.0);
   if (EVAP) {
@@ -382,6 +395,9 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
     // request everything level jk+1 needs now; nothing below touches `nxt` before the end of this level, so the
     // HBM latency is covered by the whole level's arithmetic
     if (!last) load_level<HAS_QSAT>(&ap->in, ol, nproma, nlev, jk + 1, nxt);
+#if C2_TROP_DEFER
+    if (jk == ktrop) rhcrit_setup(tropopause<PERT>(c, tab, &ap->in, o, &ap->g, lam), rh);  // wave-uniform branch
+#endif
 
     if (!HAS_QSAT) cur.qsat = satur_point<P>(c, cur.pap, cur.t);  // SATUR on the unperturbed PAP, PT
     if (PERT) perturb_raw(cur, lam);

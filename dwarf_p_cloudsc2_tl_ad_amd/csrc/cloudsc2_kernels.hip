@@ -251,13 +251,32 @@ expand_kernel(const real_t* __restrict__ table, int klon, int period, long long 
   }
 }
 
+// One (NPROMA, nrows, NBLOCKS) array from one blocking to another (resident states the library blocks differently from the caller:
+// cloudsc2_state_upload / _download).  Columns g < ncopy are copied; ncopy <= g < nzero are written as zero (whole blocks of the
+// two arrays the driver zeroes, cloudsc_driver_mod.F90:87-88); everything else keeps its value.
+__global__ void __launch_bounds__(256)
+reblock_kernel(const real_t* __restrict__ src, int np_src, long long stride_src, real_t* __restrict__ dst, int np_dst,
+               long long stride_dst, long long nrows, long long ncopy, long long nzero) {
+  const long long total = nrows * nzero;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long row = e / nzero, g = e - row * nzero;
+    const long long bd = g / np_dst, jd = g - bd * np_dst;
+    real_t v = 0;
+    if (g < ncopy) {
+      const long long bs = g / np_src, js = g - bs * np_src;
+      v = src[bs * stride_src + row * np_src + js];
+    }
+    dst[bd * stride_dst + row * np_dst + jd] = v;
+  }
+}
+
 // Per-workgroup partial statistics of VALIDATE_R2/R3 (validate_mod.F90:165-261): min and max of FIELD over whole
 // blocks (padding included, like MINVAL(FIELD(:,:,B))), max |FIELD-REF|, sum |FIELD-REF|, sum |REF| over the active
 // columns.  part[5*blockIdx.x + {0..4}]; a second launch folds the partials in a fixed order (deterministic sums).
 __global__ void __launch_bounds__(256)
 validate_partial_kernel(const real_t* __restrict__ table, int klon, int period, long long start, int nlevx, int ndim,
                         int nproma, long long ngptot, long long nblocks, const real_t* __restrict__ field,
-                        long long block_stride, double* __restrict__ part) {
+                        long long block_stride, double* __restrict__ part, long long ncols_minmax) {
   const long long per_block = (long long)nproma * nlevx * ndim;
   const long long total = per_block * nblocks;
   double vmin = INFINITY, vmax = -INFINITY, emax = 0.0, esum = 0.0, rsum = 0.0;
@@ -268,8 +287,10 @@ validate_partial_kernel(const real_t* __restrict__ table, int klon, int period, 
     const long long lev = r / nproma;
     const long long g = ibl * nproma + jl;
     const double f = field[ibl * block_stride + r];
-    vmin = fmin(vmin, f);
-    vmax = fmax(vmax, f);
+    if (g < ncols_minmax) {  // MINVAL / MAXVAL run over whole blocks of the CALLER's blocking (resident states may be blocked otherwise)
+      vmin = fmin(vmin, f);
+      vmax = fmax(vmax, f);
+    }
     if (g < ngptot) {
       const double ref = table[(start + g % period) % klon + (long long)klon * lev];
       const double d = fabs(f - ref);
@@ -337,21 +358,24 @@ __device__ __forceinline__ double wave_max(double v) {
 // sums[(ibl*10 + f)*2 + {0,1}] = { sum(F - F5), sum(TL*lambda) }.
 struct TenPtrs { const real_t* p[10]; long long stride[10]; int nlevx[10]; };
 
-__global__ void __launch_bounds__(256) taylor_sums_kernel(int nproma, int nlev, int ngptot, TenPtrs f, TenPtrs f5, TenPtrs tl,
-                                                          double lambda, double* sums) {
+// `nproma` is the block of the STATISTIC (the caller's NPROMA: ERROR_NORM sums over one NPROMA block); the arrays are blocked by
+// `nproma_phys` (the same, except for resident states the library blocks differently from the caller).
+__global__ void __launch_bounds__(256) taylor_sums_kernel(int nproma, int nproma_phys, int nlev, int ngptot, TenPtrs f, TenPtrs f5,
+                                                          TenPtrs tl, double lambda, double* sums) {
   (void)nlev;
   const int ibl = blockIdx.x;
   const int icend = min(nproma, ngptot - ibl * nproma);
   __shared__ double red[2][4];
   for (int fi = 0; fi < 10; ++fi) {
     double s0 = 0.0, s1 = 0.0;
-    const real_t* a = f.p[fi] + (long long)ibl * f.stride[fi];
-    const real_t* b = f5.p[fi] + (long long)ibl * f5.stride[fi];
-    const real_t* t = tl.p[fi] + (long long)ibl * tl.stride[fi];
     const int nl = f.nlevx[fi];
     for (int jl = threadIdx.x; jl < icend; jl += blockDim.x) {
+      const long long g = (long long)ibl * nproma + jl, pb = g / nproma_phys, pj = g - pb * nproma_phys;
+      const real_t* a = f.p[fi] + pb * f.stride[fi] + pj;
+      const real_t* b = f5.p[fi] + pb * f5.stride[fi] + pj;
+      const real_t* t = tl.p[fi] + pb * tl.stride[fi] + pj;
       for (int jk = 0; jk < nl; ++jk) {
-        long long d = (long long)jk * nproma + jl;
+        long long d = (long long)jk * nproma_phys;
         s0 += a[d] - b[d];
         s1 += t[d] * lambda;
       }
@@ -747,8 +771,18 @@ int cloudsc2_expand_launch(const cloudsc2_real* table, int klon, int period, lon
 
 int cloudsc2_validate_workspace_doubles(void) { return 5 * 2048; }
 
+static int validate_launch_impl(const cloudsc2_real* table, int klon, int period, long long start, int nlevx, int ndim, int nproma,
+                                long long ngptot, cloudsc2_field field, double* workspace, double* stats, void* stream,
+                                long long ncols_minmax);
 int cloudsc2_validate_launch(const cloudsc2_real* table, int klon, int period, long long start, int nlevx, int ndim, int nproma,
                              long long ngptot, cloudsc2_field field, double* workspace, double* stats, void* stream) {
+  return validate_launch_impl(table, klon, period, start, nlevx, ndim, nproma, ngptot, field, workspace, stats, stream, -1);
+}
+
+// ncols_minmax < 0: the field's own whole blocks
+static int validate_launch_impl(const cloudsc2_real* table, int klon, int period, long long start, int nlevx, int ndim, int nproma,
+                                long long ngptot, cloudsc2_field field, double* workspace, double* stats, void* stream,
+                                long long ncols_minmax) {
   long long nblocks;
   int rc = check_expand_args(table, klon, period, start, nlevx, ndim, nproma, ngptot, field, &nblocks);
   if (rc) return rc;
@@ -756,7 +790,8 @@ int cloudsc2_validate_launch(const cloudsc2_real* table, int klon, int period, l
   const long long total = nblocks * nproma * nlevx * ndim;
   const int nparts = (int)std::min<long long>((total + 255) / 256, 2048);
   hipLaunchKernelGGL(validate_partial_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, table, klon, period, start,
-                     nlevx, ndim, nproma, ngptot, nblocks, (const real_t*)field.ptr, field.block_stride, workspace);
+                     nlevx, ndim, nproma, ngptot, nblocks, (const real_t*)field.ptr, field.block_stride, workspace,
+                     ncols_minmax < 0 ? nblocks * nproma : ncols_minmax);
   hipLaunchKernelGGL(validate_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double*)workspace, nparts, stats);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -774,9 +809,16 @@ static int ten_ptrs(const cloudsc2_outputs* o, int nlev, TenPtrs& t) {
   return 0;
 }
 
+static int taylor_sums_launch_impl(int nproma, int nproma_phys, int nlev, int ngptot, const cloudsc2_outputs* f,
+                                   const cloudsc2_outputs* f_pert, const cloudsc2_outputs* tl, double lambda, double* sums, void* stream);
 int cloudsc2_taylor_sums_launch(int nproma, int nlev, int ngptot, const cloudsc2_outputs* f,
                                 const cloudsc2_outputs* f_pert, const cloudsc2_outputs* tl, double lambda,
                                 double* sums, void* stream) {
+  return taylor_sums_launch_impl(nproma, nproma, nlev, ngptot, f, f_pert, tl, lambda, sums, stream);
+}
+
+static int taylor_sums_launch_impl(int nproma, int nproma_phys, int nlev, int ngptot, const cloudsc2_outputs* f,
+                                   const cloudsc2_outputs* f_pert, const cloudsc2_outputs* tl, double lambda, double* sums, void* stream) {
   if (!f || !f_pert || !tl || !sums) return fail(CLOUDSC2_EINVAL, "NULL argument");
   if (!device_ok()) return fail(CLOUDSC2_ENODEVICE, "no HIP device available (this library has no CPU path)");
   TenPtrs a, b, c;
@@ -785,8 +827,8 @@ int cloudsc2_taylor_sums_launch(int nproma, int nlev, int ngptot, const cloudsc2
   if ((rc = ten_ptrs(f_pert, nlev, b))) return rc;
   if ((rc = ten_ptrs(tl, nlev, c))) return rc;
   int nblocks = (ngptot + nproma - 1) / nproma;
-  hipLaunchKernelGGL(taylor_sums_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, nproma, nlev, ngptot, a, b, c,
-                     lambda, sums);
+  hipLaunchKernelGGL(taylor_sums_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, nproma, nproma_phys, nlev, ngptot, a, b,
+                     c, lambda, sums);
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -336,8 +336,15 @@ struct LevelCst {
 };
 
 // Per-column critical-RH set-up, depends only on ZTRPAUS (cloudsc2.F90:384-390).
+// C2_RHCRIT_RCP (fast arithmetic only): the two quotients of the level's critical-RH profile become products with
+// reciprocals taken once per column (1/ZDETA1) or at compile time (1/ZDETA2) -- two IEEE fp64 divisions (~2 x 14 vector
+// instructions in lane-divergent branches) less per level.
+#ifndef C2_RHCRIT_RCP
+#define C2_RHCRIT_RCP 1
+#endif
 struct RhCrit {
   real_t zeta3, zrh2, zdeta1;
+  real_t rzdeta1;  // 1/ZDETA1
 };
 
 C2_HD void rhcrit_setup(real_t ztrpaus, RhCrit& r) {
@@ -346,20 +353,23 @@ C2_HD void rhcrit_setup(real_t ztrpaus, RhCrit& r) {
   real_t dq = d / RC(0.15);
   r.zrh2 = RC(0.35) + RC(0.14) * (dq * dq) + RC(0.04) * fmin(d, RC(0.0)) / RC(0.15);
   r.zdeta1 = RC(0.09) + RC(0.16) * (RC(0.4) - ztrpaus) / RC(0.3);
+  r.rzdeta1 = RC(1.0) / r.zdeta1;
 }
 
+template <bool P>
 C2_HD real_t rhcrit_level(const RhCrit& r, real_t ceta) {
   // cloudsc2.F90:391-399 (ZRH1 = ZRH3 = 1, ZDETA2 = 0.3)
   const real_t zdeta2 = RC(0.3);
+  constexpr bool RCP = !P && (C2_RHCRIT_RCP != 0);
   real_t zcrh2 = RC(1.0);
   if (ceta < r.zeta3) {
     zcrh2 = RC(1.0);
   } else if (ceta < (r.zeta3 + zdeta2)) {
-    zcrh2 = RC(1.0) + (r.zrh2 - RC(1.0)) * ((ceta - r.zeta3) / zdeta2);
+    zcrh2 = RC(1.0) + (r.zrh2 - RC(1.0)) * (RCP ? (ceta - r.zeta3) * (RC(1.0) / zdeta2) : (ceta - r.zeta3) / zdeta2);
   } else if (ceta < (RC(1.0) - r.zdeta1)) {
     zcrh2 = r.zrh2;
   } else {
-    zcrh2 = RC(1.0) + (r.zrh2 - RC(1.0)) * sqrt((RC(1.0) - ceta) / r.zdeta1);
+    zcrh2 = RC(1.0) + (r.zrh2 - RC(1.0)) * sqrt(RCP ? (RC(1.0) - ceta) * r.rzdeta1 : (RC(1.0) - ceta) / r.zdeta1);
   }
   return zcrh2;
 }
@@ -367,6 +377,9 @@ C2_HD real_t rhcrit_level(const RhCrit& r, real_t ceta) {
 template <bool PRECISE>
 C2_HD real_t ex(real_t x) { return PRECISE ? exp(x) : c2_exp(x); }
 
+#ifndef C2_SATUR_UNIFORM
+#define C2_SATUR_UNIFORM 0
+#endif
 // FOEALFA (src/common/include/fcttre.func.h:74-75)
 C2_HD real_t foealfa(ConstsP c, real_t t) {
   real_t x = (fmax(c->rtice, fmin(c->rtwat, t)) - c->rtice) * c->rtwat_rtice_r;
@@ -397,10 +410,20 @@ C2_HD real_t satur_point(ConstsP c, real_t pap, real_t t) {
     real_t rl, ri, rp;
     c2_rcp3(t - r4les, t - r4ies, pap, rl, ri, rp);
     real_t dt = t - rtt;
-    // both branches unconditionally: a lane-divergent skip of the zero-weight exp costs more (the constant block is
-    // re-fetched inside every branch) than the ~20 instructions it saves
+    // both exps unconditionally per LANE: a lane-divergent skip of the zero-weight exp costs more (the constant block is
+    // re-fetched inside every branch) than the ~20 instructions it saves.  C2_SATUR_UNIFORM: skipped when NO lane of the wave
+    // needs it (all lanes at or below RTICE: no liquid part; all at or above RTWAT: no ice part) -- a scalar branch on a ballot,
+    // taken by whole waves on most levels of an atmosphere (cold aloft, warm below).  The skipped term has weight exactly 0, so
+    // the result keeps its bits.
+#if C2_SATUR_UNIFORM && defined(__HIP_DEVICE_COMPILE__)
+    zfoeewl = RC(0.0);
+    zfoeewi = RC(0.0);
+    if (__builtin_amdgcn_ballot_w64(zalfa > RC(0.0)) != 0) zfoeewl = r2es * c2_exp(r3les * dt * rl);
+    if (__builtin_amdgcn_ballot_w64(zalfa < RC(1.0)) != 0) zfoeewi = r2es * c2_exp(r3ies * dt * ri);
+#else
     zfoeewl = r2es * c2_exp(r3les * dt * rl);
     zfoeewi = r2es * c2_exp(r3ies * dt * ri);
+#endif
     real_t zfoeew = zalfa * zfoeewl + (RC(1.0) - zalfa) * zfoeewi;
     zqs = zfoeew * rp;
     if (zqs > RC(0.5)) zqs = RC(0.5);
@@ -565,7 +588,7 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
   }
 
   // B. critical relative humidity (cloudsc2.F90:384-407)
-  t.zcrh2 = rhcrit_level(rh, k.ceta);
+  t.zcrh2 = rhcrit_level<P>(rh, k.ceta);
   t.below_rtice = t.ztp2 < k1.v[K1_RTICE];
   t.zsupsat = t.below_rtice ? (RC(1.8) - RC(3.e-03) * t.ztp2) : RC(1.0);
   t.zqsat = x.qs * t.zsupsat;

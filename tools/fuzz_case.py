@@ -10,15 +10,11 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from tests.test_gpu_parity import checker, ref_nl_state  # noqa: E402
 from tests.util import c2, set_lib_params  # noqa: E402
 
+from tests.fuzz_cases import cases  # noqa: E402
+
 case = int(sys.argv[1])
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
-for it in range(case + 1):
-    nlev = int(rng.choice([137, 137, 91, 60, 30, 200]))
-    ncol = int(rng.integers(20, 90))
-    nproma = int(rng.choice([1, 7, 16, 33, 64, 100, 128, 192]))
-    ngptot = int(rng.integers(max(2, nproma // 2), 3 * nproma + 40))
-    flags = dict(lregcl=bool(rng.integers(2)), levapls2=bool(rng.integers(2)), ldrain1d=bool(rng.integers(4) == 0))
-    seed = int(rng.integers(1 << 30))
+c = cases(int(sys.argv[2]) if len(sys.argv) > 2 else 2026, case + 1)[case]
+nlev, ncol, nproma, ngptot, flags, seed = c["nlev"], c["ncol"], c["nproma"], c["ngptot"], c["flags"], c["table_seed"]
 print(f"case {case}: nlev {nlev} ncol {ncol} nproma {nproma} ngptot {ngptot} {flags} table seed {seed}")
 tab = c2.random_table(nlev, ncol, seed=seed)
 prm = c2.default_params(c2.ceta_from_table(tab), **flags)
