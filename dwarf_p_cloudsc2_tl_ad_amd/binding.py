@@ -144,6 +144,8 @@ def _load() -> C.CDLL:
     lib.cloudsc2_state_destroy.argtypes = [C.c_void_p]
     lib.cloudsc2_state_destroy.restype = None
     lib.cloudsc2_state_field.argtypes = [C.c_void_p, C.c_int, C.POINTER(Field)]
+    lib.cloudsc2_state_blocking.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.cloudsc2_state_blocking.restype = C.c_int
     lib.cloudsc2_state_expand.argtypes = [C.c_void_p, C.c_int, rp, C.c_int, C.c_int, C.c_longlong]
     lib.cloudsc2_state_upload.argtypes = [C.c_void_p] + host18
     lib.cloudsc2_state_download.argtypes = [C.c_void_p] + [rp] * 7
@@ -197,7 +199,7 @@ EXPORTED = ("cloudsc2_params_default", "cloudsc2_last_error", "cloudsc2_device_a
             "cloudsc2_expand_launch", "cloudsc2_validate_workspace_doubles", "cloudsc2_validate_launch",
             "cloudsc2_expand_offsets", "cloudsc2_validate_relerr", "cloudsc2_validate_format", "cloudsc2_validate_header",
             "cloudsc2_device_malloc", "cloudsc2_device_free", "cloudsc2_device_malloc_info", "cloudsc2_device_probe", "cloudsc2_device_malloc_state",
-            "cloudsc2_state_create", "cloudsc2_state_destroy", "cloudsc2_state_field", "cloudsc2_state_expand",
+            "cloudsc2_state_create", "cloudsc2_state_destroy", "cloudsc2_state_field", "cloudsc2_state_blocking", "cloudsc2_state_expand",
             "cloudsc2_state_upload", "cloudsc2_state_download", "cloudsc2_state_nl", "cloudsc2_state_tl_taylor",
             "cloudsc2_state_ad_symmetry", "cloudsc2_state_validate")
 

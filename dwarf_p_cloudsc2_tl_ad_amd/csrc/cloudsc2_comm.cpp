@@ -79,8 +79,44 @@ std::string rendezvous_name(const char* suffix) {
   return buf;
 }
 
+// What tells this job's rendezvous file / segment from a leftover of a crashed one with the same name (MASTER_PORT "0" under
+// mpirun / srun, a reused launcher pid): a nonce every rank of ONE launch derives alike -- the launcher's own name for the job if it
+// gave one (CLOUDSC2_COMM_TOKEN, TORCHELASTIC_RUN_ID), else MASTER_PORT + the launcher's pid + the launcher's START TIME
+// (/proc/<ppid>/stat field 22), which a later process with the same pid does not share.  Readers wait until they see it.
+// Single node only: pid, /proc, /tmp and POSIX shared memory are per node (one node of 8 GPUs is the dwarf's scope);
+// across nodes hand the id in through cloudsc2_comm_init_rank.
+unsigned long long job_nonce() {
+  unsigned long long h = 1469598103934665603ull;
+  auto mix = [&](const char* s) { for (; s && *s; ++s) { h ^= (unsigned char)*s; h *= 1099511628211ull; } h ^= 0xff; h *= 1099511628211ull; };
+  const char* token = getenv("CLOUDSC2_COMM_TOKEN");
+  const char* run = getenv("TORCHELASTIC_RUN_ID");
+  if (token && *token) { mix("token"); mix(token); }
+  else if (run && *run && strcmp(run, "none") != 0) { mix("run"); mix(run); mix(getenv("MASTER_PORT")); }
+  else {
+    char buf[1024], path[64];
+    snprintf(buf, sizeof buf, "%ld", (long)getppid());
+    mix("ppid"); mix(buf); mix(getenv("MASTER_PORT"));
+    snprintf(path, sizeof path, "/proc/%ld/stat", (long)getppid());
+    if (FILE* f = fopen(path, "r")) {
+      const size_t n = fread(buf, 1, sizeof buf - 1, f);
+      fclose(f);
+      buf[n] = 0;
+      const char* q = strrchr(buf, ')');  // the command name may contain blanks and parentheses
+      int field = 2;
+      for (q = q ? q + 1 : buf; *q && field < 22; ++q) if (*q == ' ' && q[1] != ' ') ++field;
+      char start[32] = {0};
+      for (int i = 0; i < 31 && q[i] && q[i] != ' '; ++i) start[i] = q[i];
+      mix(start);
+    }
+  }
+  return h ? h : 1;  // 0 means "not published yet" in a fresh (zero-filled) segment
+}
+constexpr unsigned long long kIdMagic = 0x32435344554f4c43ull;  // "CLOUDSC2"
+struct IdFile { unsigned long long magic, nonce; ncclUniqueId id; };
+
 // ---- shared-memory transport (rehearsal: more ranks than GPUs) -------------------------------------------------------
 struct ShmSeg {
+  std::atomic<unsigned long long> nonce;  // job_nonce(), stored by rank 0 once the segment is ready
   std::atomic<int> arrived;   // barrier counter
   std::atomic<int> sense;     // barrier generation
   std::atomic<int> attached;
@@ -111,25 +147,36 @@ int shm_open_segment() {
   std::string n = rendezvous_name(".shm");
   for (auto& c : n) if (c == '/') c = '_';
   g_shm_name = "/" + n;
-  int fd = -1;
+  const unsigned long long nonce = job_nonce();
   if (g_rank == 0) {
-    shm_unlink(g_shm_name.c_str());
-    fd = shm_open(g_shm_name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
-    if (fd < 0 || ftruncate(fd, sizeof(ShmSeg)) != 0) return fail(CLOUDSC2_COMM_EINVAL, "shm_open/ftruncate failed for " + g_shm_name);
+    shm_unlink(g_shm_name.c_str());  // a leftover of a crashed job: ranks that already opened it see the wrong nonce and retry
+    const int fd = shm_open(g_shm_name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, sizeof(ShmSeg)) != 0) { if (fd >= 0) close(fd); return fail(CLOUDSC2_COMM_EINVAL, "shm_open/ftruncate failed for " + g_shm_name); }
+    void* p = mmap(nullptr, sizeof(ShmSeg), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) return fail(CLOUDSC2_COMM_EINVAL, "mmap of the shm segment failed");
+    g_shm = (ShmSeg*)p;
+    g_shm->world = g_world;      // (a fresh segment is zero-filled: counters start at 0)
+    g_shm->nonce.store(nonce);   // ready
   } else {
     const double t0 = now_s();
-    struct stat sb;
-    while ((fd = shm_open(g_shm_name.c_str(), O_RDWR, 0600)) < 0 || fstat(fd, &sb) != 0 || (size_t)sb.st_size < sizeof(ShmSeg)) {
-      if (fd >= 0) { close(fd); fd = -1; }
-      if (now_s() - t0 > 120.0) return fail(CLOUDSC2_COMM_ETIMEOUT, "rank 0 did not create " + g_shm_name + " within 120 s");
+    for (;;) {  // until THIS job's segment is there: same name, this launch's nonce, owned by this user
+      struct stat sb;
+      const int fd = shm_open(g_shm_name.c_str(), O_RDWR, 0600);
+      if (fd >= 0 && fstat(fd, &sb) == 0 && (size_t)sb.st_size >= sizeof(ShmSeg) && sb.st_uid == geteuid()) {
+        void* p = mmap(nullptr, sizeof(ShmSeg), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (p != MAP_FAILED) {
+          if (((ShmSeg*)p)->nonce.load() == nonce) { g_shm = (ShmSeg*)p; break; }
+          munmap(p, sizeof(ShmSeg));  // a stale segment (or rank 0 has not finished): look the name up again
+        }
+      } else if (fd >= 0) {
+        close(fd);
+      }
+      if (now_s() - t0 > 120.0) return fail(CLOUDSC2_COMM_ETIMEOUT, "rank 0 did not create " + g_shm_name + " (for this launch) within 120 s");
       usleep(1000);
     }
   }
-  void* p = mmap(nullptr, sizeof(ShmSeg), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-  close(fd);
-  if (p == MAP_FAILED) return fail(CLOUDSC2_COMM_EINVAL, "mmap of the shm segment failed");
-  g_shm = (ShmSeg*)p;
-  if (g_rank == 0) g_shm->world = g_world;  // (a fresh segment is zero-filled: counters start at 0)
   g_shm->attached.fetch_add(1);
   const double t0 = now_s();
   while (g_shm->attached.load() < g_world) {
@@ -173,24 +220,34 @@ int rccl_setup(const ncclUniqueId& id) {
 
 int publish_or_fetch_id(ncclUniqueId* id) {
   g_id_file = rendezvous_name(".id");
+  IdFile rec;
+  rec.magic = kIdMagic;
+  rec.nonce = job_nonce();
   if (g_rank == 0) {
     NCCL_TRY(ncclGetUniqueId(id));
-    const std::string tmp = g_id_file + ".tmp";
-    FILE* f = fopen(tmp.c_str(), "wb");
-    if (!f || fwrite(id, sizeof(*id), 1, f) != 1) { if (f) fclose(f); return fail(CLOUDSC2_COMM_EINVAL, "cannot write " + tmp); }
-    fclose(f);
-    if (rename(tmp.c_str(), g_id_file.c_str()) != 0) return fail(CLOUDSC2_COMM_EINVAL, "cannot publish " + g_id_file);
+    rec.id = *id;
+    // written under a private name (created exclusively, never through a symlink, readable by this user only), then renamed over
+    // whatever a crashed job may have left under the public one: readers see the old record (wrong nonce: ignored) or the new one
+    const std::string tmp = g_id_file + ".tmp." + std::to_string((long)getpid());
+    unlink(tmp.c_str());
+    const int fd = open(tmp.c_str(), O_CREAT | O_EXCL | O_NOFOLLOW | O_WRONLY, 0600);
+    if (fd < 0 || write(fd, &rec, sizeof rec) != (ssize_t)sizeof rec) { if (fd >= 0) close(fd); unlink(tmp.c_str()); return fail(CLOUDSC2_COMM_EINVAL, "cannot write " + tmp); }
+    close(fd);
+    if (rename(tmp.c_str(), g_id_file.c_str()) != 0) { unlink(tmp.c_str()); return fail(CLOUDSC2_COMM_EINVAL, "cannot publish " + g_id_file); }
     return 0;
   }
   const double t0 = now_s();
   for (;;) {
-    FILE* f = fopen(g_id_file.c_str(), "rb");
-    if (f) {
-      const size_t got = fread(id, sizeof(*id), 1, f);
-      fclose(f);
-      if (got == 1) return 0;
+    const int fd = open(g_id_file.c_str(), O_RDONLY | O_NOFOLLOW);
+    if (fd >= 0) {
+      struct stat sb;
+      IdFile got;
+      const bool ok = fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_uid == geteuid() && read(fd, &got, sizeof got) == (ssize_t)sizeof got &&
+                      got.magic == kIdMagic && got.nonce == rec.nonce;
+      close(fd);
+      if (ok) { *id = got.id; return 0; }
     }
-    if (now_s() - t0 > 120.0) return fail(CLOUDSC2_COMM_ETIMEOUT, "rank 0 did not publish " + g_id_file + " within 120 s");
+    if (now_s() - t0 > 120.0) return fail(CLOUDSC2_COMM_ETIMEOUT, "rank 0 did not publish " + g_id_file + " (for this launch) within 120 s");
     usleep(2000);
   }
 }

@@ -399,6 +399,12 @@ class ResidentState:
             B.check(B.lib.cloudsc2_state_expand(self.h, fid, _ptr(t), klon, klon if period is None else period, start))
         return self
 
+    def blocking(self):
+        """(NPROMA of the device arrays -- the library's choice --, the caller's NPROMA)"""
+        d, u = C.c_int(), C.c_int()
+        B.check(B.lib.cloudsc2_state_blocking(self.h, C.byref(d), C.byref(u)))
+        return d.value, u.value
+
     def nl(self, prm: B.Params, repeats: int = 1) -> float:
         ms = C.c_double()
         B.check(B.lib.cloudsc2_state_nl(self.h, C.byref(prm), self.ptsphy, int(repeats), C.byref(ms)))

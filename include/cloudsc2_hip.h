@@ -269,7 +269,13 @@ void cloudsc2_release_workspace(void);
  *                             on the resident state (their scratch arrays are a second allocation owned by the handle).
  *   cloudsc2_state_validate   VALIDATE_R2/R3 (validate_mod.F90:165-261) of one field against a KLON-column HOST reference
  *                             table (KLON, NLEVx, ndim): stats[5] as cloudsc2_validate_launch.
- *   cloudsc2_state_field      the device pointer + block stride of one field, for the kernel-level entry points.
+ *   cloudsc2_state_field      the device pointer + block stride of one field, for the kernel-level entry points -- in the
+ *                             DEVICE blocking (cloudsc2_state_blocking), which is the library's choice, see below.
+ * Blocking.  `nproma` of cloudsc2_state_create is the CALLER's NPROMA: the blocking of the host arrays of _upload / _download, the
+ * block ERROR_NORM of the Taylor test sums over (cloudsc_driver_tl_mod.F90:21-31) and the blocks whose padding MINVAL / MAXVAL of
+ * the validator see (validate_mod.F90:186-187).  The device arrays themselves are blocked for the kernels: the caller's NPROMA
+ * when it is a multiple of 64, else 128 (CLOUDSC2_STATE_NPROMA=0: always the caller's) -- every column is independent, so the
+ * results are the same bits whatever the blocking, and NPROMA 32 (the reference README's) or 100 cost the TL / AD sweeps 8 %.
  * A handle belongs to the HIP device that was current when it was created; calls are synchronous.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct cloudsc2_state cloudsc2_state;
@@ -284,6 +290,7 @@ enum {
 int cloudsc2_state_create(int nproma, int nlev, int ngptot, cloudsc2_state** state);
 void cloudsc2_state_destroy(cloudsc2_state* state);
 int cloudsc2_state_field(const cloudsc2_state* state, int field, cloudsc2_field* f);
+int cloudsc2_state_blocking(const cloudsc2_state* state, int* nproma_device, int* nproma_caller);
 int cloudsc2_state_expand(cloudsc2_state* state, int field, const cloudsc2_real* table, int klon, int period, long long start);
 int cloudsc2_state_upload(cloudsc2_state* state,
                           const cloudsc2_real* pt, const cloudsc2_real* pq, const cloudsc2_real* b_cml, cloudsc2_real* b_loc,

@@ -75,3 +75,37 @@ def test_three_ranks_reduce_and_gather_over_the_rehearsal_transport(tmp_path):
         assert d["gather"] == [[0, 100], [1, 101], [2, 102]]
         assert d["loop"] == [3.0]
     assert res[0]["sum"] == res[1]["sum"] == res[2]["sum"]  # fixed reduction order: identical bits on every rank
+
+
+def test_a_leftover_segment_of_a_crashed_job_is_not_mistaken_for_this_one():
+    """Same rendezvous name as a job that died (no MASTER_PORT under mpirun, a reused launcher pid): the stale POSIX segment is
+    there before any rank starts, full of another launch's counters.  Ranks != 0 must not attach to it (they used to, and then
+    waited for ranks that never come): the segment carries the launch's nonce, rank 0 replaces it, the others wait for theirs."""
+    import json
+
+    world = 2
+    # no CLOUDSC2_COMM_TOKEN: the name comes from MASTER_PORT + this process's pid, the nonce also from this process's start time
+    name = f"/_tmp_cloudsc2_comm_29889_{os.getpid()}.shm"
+    path = "/dev/shm" + name
+    with open(path, "wb") as f:  # what a crashed 4-rank job left: wrong nonce, everybody "attached", barrier mid-flight
+        f.write((0x1234567812345678).to_bytes(8, "little") + (3).to_bytes(4, "little") + (1).to_bytes(4, "little") + (4).to_bytes(4, "little")
+                + (4).to_bytes(4, "little") + bytes(64 * 64 * 8))
+    try:
+        procs = []
+        for rank in (1, 0):  # rank 1 first: it finds the stale segment before rank 0 has replaced it
+            env = {k: v for k, v in os.environ.items() if k not in ("CLOUDSC2_COMM_TOKEN", "TORCHELASTIC_RUN_ID")}
+            env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_PORT="29889", CLOUDSC2_COMM="shm")
+            procs.append(subprocess.Popen([sys.executable, "-c", WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+            if rank == 1:
+                import time
+
+                time.sleep(1.5)
+        outs = [p.communicate(timeout=180) for p in procs]
+        for p, (so, se) in zip(procs, outs):
+            assert p.returncode == 0, se[-2000:]
+        for so, _ in outs:
+            d = json.loads(so.split("RESULT ", 1)[1])
+            assert d["world"] == 2 and d["max"] == [2.0, 0.0, 10.0] and d["loop"] == [1.0]
+    finally:
+        if os.path.exists(path):
+            os.unlink(path)

@@ -299,18 +299,21 @@ def test_cpp_host_example_prints_the_same_report(tmp_path):
     assert r.stdout.rstrip("\n") == text
 
 
-def test_resident_state_handle_equals_the_host_pointer_drivers():
+@pytest.mark.parametrize("nproma,ngptot", [(96, 1000), (32, 1000), (100, 1000), (128, 1000), (1, 100), (1000, 2500)])
+def test_resident_state_handle_equals_the_host_pointer_drivers(nproma, ngptot):
     """cloudsc2_state_* (the library-owned resident GLOBAL_STATE the Fortran mains use with CLOUDSC2_RESIDENT=1): expand from
     the KLON-column tables, NL, download == the host-pointer driver on the host-tiled state, bit for bit; the two self-tests
     return the same norms as cloudsc2_tl_taylor_run / cloudsc2_ad_symmetry_run; validation against the state's own outputs
-    gives zero error; upload of a host state gives the same results as expand."""
+    gives zero error; upload of a host state gives the same results as expand.  The device arrays are blocked by the library
+    (128 unless the caller's NPROMA is a multiple of 64): host arrays, the Taylor statistic's blocks and the validator's
+    MINVAL / MAXVAL keep the caller's blocking."""
     tab = c2.synthetic_table()
-    nproma, ngptot = 96, 1000
     prm = c2.default_params(c2.ceta_from_table(tab))
     want = c2.state_from_table(tab, nproma, ngptot, poison_outputs=3.0)
     c2.run_state(prm, want, "nl")
 
     rs = c2.ResidentState.from_table(tab, nproma, ngptot)
+    assert rs.blocking() == (nproma if nproma % 64 == 0 else 128, nproma)
     ms = rs.nl(prm, repeats=3)
     assert ms > 0.0
     got = rs.download(c2.state_from_table(tab, nproma, ngptot, poison_outputs=3.0))
@@ -320,8 +323,11 @@ def test_resident_state_handle_equals_the_host_pointer_drivers():
     cols = got.PFPLSN.transpose(0, 2, 1).reshape(-1, got.nlev + 1)[:100]  # (column, level)
     st = rs.validate(B.F_FULL["PFPLSN"], np.ascontiguousarray(cols.T))
     assert st[2] == 0.0 and st[3] == 0.0 and st[4] > 0.0
-    act = got.PFPLSN.transpose(0, 2, 1).reshape(-1, got.nlev + 1)[:ngptot]  # the padded tail is zero on the device (FIELD_INIT)
-    assert st[0] == min(act.min(), 0.0) and st[1] == max(act.max(), 0.0)
+    act = got.PFPLSN.transpose(0, 2, 1).reshape(-1, got.nlev + 1)[:ngptot]
+    if got.nblocks * nproma > ngptot:  # MINVAL / MAXVAL see the zero padding (FIELD_INIT) of the CALLER's last block, if it has any
+        assert st[0] == min(act.min(), 0.0) and st[1] == max(act.max(), 0.0)
+    else:
+        assert st[0] == act.min() and st[1] == act.max()
 
     # the self-tests on the resident state vs. on host arrays
     prm_tl = c2.default_params(c2.ceta_from_table(tab), lregcl=False)
@@ -399,3 +405,14 @@ def test_device_allocator_places_and_frees():
     r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "CLOUDSC2_PLACE_MODE": "chunks"}, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
     assert int(r.stdout.split()[1]) >= 11 and int(r.stdout.split()[2]) == 3 * 4096
+    # the search's transient footprint is bounded where the host model says so, and nothing is searched on a device that other
+    # ranks allocate on at the same time (hipMemGetInfo and hipMalloc are not coordinated between processes)
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from dwarf_p_cloudsc2_tl_ad_amd import binding as B\n"
+            "b = B.DeviceBuffer(3 << 30); print('OK', B.device_malloc_info()['candidates'])\n" % ROOT)
+    for env, want in (({"CLOUDSC2_PLACE_MAX_GB": "7"}, 2), ({"CLOUDSC2_PLACE_SHARED": "1"}, 1), ({"LOCAL_WORLD_SIZE": "64"}, 1),
+                      ({"CLOUDSC2_PLACE_MAX_SHARE": "0.001"}, 1)):
+        r = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and r.stdout.split()[:1] == ["OK"], r.stdout + r.stderr
+        # (the second batch of candidates, taken when the first shows no class difference, shares the budget: at most `want`)
+        assert 1 <= int(r.stdout.split()[1]) <= want, (env, r.stdout)
