@@ -206,9 +206,6 @@ C2_HD void make_level_in(const RawLevel& cur, real_t paph_k, real_t paph_surf, L
 #ifndef C2_TROP_BATCH
 #define C2_TROP_BATCH 16
 #endif
-#ifndef C2_TROP_DEFER
-#define C2_TROP_DEFER 0
-#endif
 template <bool PERT>
 C2_HD real_t tropopause(ConstsP c, LevelTabP tab, InPtrsP p, const LaneOff& o, GeomP g, real_t lam) {
   real_t ztrpaus = RC(0.1);
@@ -293,6 +290,7 @@ enum : unsigned {
   C2F_ASSIGN = 8u,   // AD only: the input adjoints are ASSIGNED (x = A^T y) instead of accumulated (x += A^T y): their old
                      // values are neither read nor needed to be zero (the adjoint test zeroes them first, cloudsc_driver_ad_mod.F90:198-213)
   C2F_OFF32 = 32u,   // every buffer of the launch < 4 GiB: 32-bit byte offsets (LaneOff32)
+  C2F_NOLIN = 64u,   // NL only: .NOT.(LPHYLIN .OR. LDRAIN1D), the FOEALFA / FOEEWM form of stage A (cloudsc2.F90:365-369)
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -327,9 +325,10 @@ C2_HD void satur_column(long long gcol, SaturArgsP a) {
 template <unsigned F>
 C2_HD void nl_column(long long gcol, NlArgsP a) {
   constexpr bool HAS_QSAT = (F & C2F_QSAT) != 0, PERT = (F & C2F_PERT) != 0, P = (F & C2F_PRECISE) != 0, CKPT = (F & C2F_CKPT) != 0, EVAP = (F & C2F_EVAP) != 0;
-  constexpr bool OFF32 = (F & C2F_OFF32) != 0;
+  constexpr bool OFF32 = (F & C2F_OFF32) != 0, LIN = (F & C2F_NOLIN) == 0;
   typedef typename std::conditional<OFF32, unsigned, long long>::type OT;
   static_assert(!(PERT && CKPT), "the adjoint's trajectory pass is never perturbed");
+  static_assert(LIN || !CKPT, "CLOUDSC2AD's trajectory has the LPHYLIN form only");
   LaneOff o; bool active;
   if (!lane_setup(&a->g, &a->s, gcol, o, active)) return;
   const int nlev = a->g.nlev, nproma = a->g.nproma;
@@ -358,19 +357,12 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
   real_t* ckpt = (CKPT && EVAP) ? a->ckpt : nullptr;
   const long long osc = (CKPT && EVAP) ? (gcol / nproma) * ((long long)nproma * nlev) + (gcol % nproma) : 0;
 
-  // ZTRPAUS (cloudsc2.F90:315-326) is only read by levels with CETA >= ZETA3 >= 0.1 (:391-399: above that ZCRH2 = 1 whatever it
-  // is), i.e. from the first band level kb0 on.  C2_TROP_DEFER: the band's pre-scan runs when the sweep reaches kb0 instead of
-  // before level 1 -- the waves of a launch then do it at different moments instead of all at once at the start, and the main
-  // sweep re-reads the band's rows soon after the pre-scan fetched them.
-#if C2_TROP_DEFER
-  const int ktrop = a->g.kb1 > a->g.kb0 ? a->g.kb0 : 0;
-  RhCrit rh;
-  rhcrit_setup(RC(1.0), rh);  // placeholder: every level before kb0 has CETA <= 0.1 < ZETA3
-#else
+  // (ZTRPAUS is only read from the first band level on -- above it ZCRH2 = 1 whatever it is, cloudsc2.F90:391-399 -- so the pre-scan
+  // could run when the sweep reaches the band instead of before level 1: measured equal at 160 000 columns and 1.5 % slower at 1 M,
+  // like two other instruction-count candidates -- profiles/r03_b_nl_instruction_candidates_ab.txt.)
   real_t ztrpaus = tropopause<PERT>(c, tab, in, o, &a->g, lam);
   RhCrit rh;
   rhcrit_setup(ztrpaus, rh);
-#endif
 
   real_t paph_surf = RC(0.0);
   if (EVAP) {
@@ -395,9 +387,6 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
     // request everything level jk+1 needs now; nothing below touches `nxt` before the end of this level, so the
     // HBM latency is covered by the whole level's arithmetic
     if (!last) load_level<HAS_QSAT>(&ap->in, ol, nproma, nlev, jk + 1, nxt);
-#if C2_TROP_DEFER
-    if (jk == ktrop) rhcrit_setup(tropopause<PERT>(c, tab, &ap->in, o, &ap->g, lam), rh);  // wave-uniform branch
-#endif
 
     if (!HAS_QSAT) cur.qsat = satur_point<P>(c, cur.pap, cur.t);  // SATUR on the unperturbed PAP, PT
     if (PERT) perturb_raw(cur, lam);
@@ -419,7 +408,7 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
       (void)tr; (void)k; (void)rh;
     }
 #else
-    level_forward<P, EVAP>(c, k, rh, x, cy, tr, lo);
+    level_forward<P, EVAP, LIN>(c, k, rh, x, cy, tr, lo);
 #endif
     C2_LAUNDER(ap);
     store_out(&ap->out, ol, nproma, jk, lo);

@@ -219,7 +219,7 @@ template <class Args> using KernelFn = void (*)(Args);
       std::integer_sequence<unsigned, F...>) { return {{table##_entry<F>()...}}; }                                 \
   [[maybe_unused]] const std::array<KernelFn<Args>, NF> table = table##_make(std::make_integer_sequence<unsigned, NF>{});
 // (the trajectory pass differs from the plain NL sweep only with the evaporation branch: the cover checkpoint)
-C2_VARIANT_TABLE(g_nl_kernels, nl_kernel, NlArgs, 64, !(F & C2F_CKPT) || ((F & C2F_EVAP) && !(F & C2F_PERT)))
+C2_VARIANT_TABLE(g_nl_kernels, nl_kernel, NlArgs, 128, (F & C2F_CKPT) ? ((F & C2F_EVAP) && !(F & (C2F_PERT | C2F_NOLIN))) : true)
 C2_VARIANT_TABLE(g_tl_kernels, tl_kernel, TlArgs, 64, !(F & 16u))
 C2_VARIANT_TABLE(g_ad_reverse_kernels, ad_reverse_kernel, AdArgs, 64, !(F & 16u))
 C2_VARIANT_TABLE(g_ad_kernels, ad_kernel, AdArgs, 64, C2_AD_FUSED != 0 && !(F & 16u))
@@ -493,7 +493,6 @@ int check_geom(const cloudsc2_params* prm, int nproma, int nlev, int ngptot, Geo
   if (nlev > CLOUDSC2_MAX_NLEV) return fail(CLOUDSC2_EINVAL, "nlev exceeds CLOUDSC2_MAX_NLEV");
   if (prm->nlev != nlev) return fail(CLOUDSC2_EINVAL, "params.nlev does not match nlev");
   if (prm->math_mode < 0 || prm->math_mode > 2) return fail(CLOUDSC2_EINVAL, "params.math_mode must be 0 (default), 1 (fast) or 2 (precise)");
-  if (!prm->lphylin) return fail(CLOUDSC2_EINVAL, "LPHYLIN=.false. is not supported (every reference main forces .true.)");
   if (!device_ok()) return fail(CLOUDSC2_ENODEVICE, "no HIP device available (this library has no CPU path)");
   long long nblocks = ((long long)ngptot + nproma - 1) / nproma;
   g.nproma = nproma; g.nlev = nlev; g.ngptot = ngptot; g.ncols_pad = nblocks * nproma;
@@ -625,6 +624,7 @@ int cloudsc2_nl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
   if (pert_lambda != 0.0) f |= C2F_PERT;
   if (precise_of(prm)) f |= C2F_PRECISE;
   if (args.c.evap) f |= C2F_EVAP;
+  if (!prm->lphylin && !prm->ldrain1d) f |= C2F_NOLIN;  // cloudsc2.F90:349 (CLOUDSC2TL / CLOUDSC2AD have the LPHYLIN form only)
   if (fits_off32(g, nproma, nlev, {s.full, s.half, s.cml, s.clv, s.loc, (long long)zero_plane.block_stride})) f |= C2F_OFF32;
   return launch_variant(g_nl_kernels[f], args, g.ncols_pad, (hipStream_t)stream);
 }

@@ -336,15 +336,8 @@ struct LevelCst {
 };
 
 // Per-column critical-RH set-up, depends only on ZTRPAUS (cloudsc2.F90:384-390).
-// C2_RHCRIT_RCP (fast arithmetic only): the two quotients of the level's critical-RH profile become products with
-// reciprocals taken once per column (1/ZDETA1) or at compile time (1/ZDETA2) -- two IEEE fp64 divisions (~2 x 14 vector
-// instructions in lane-divergent branches) less per level.
-#ifndef C2_RHCRIT_RCP
-#define C2_RHCRIT_RCP 1
-#endif
 struct RhCrit {
   real_t zeta3, zrh2, zdeta1;
-  real_t rzdeta1;  // 1/ZDETA1
 };
 
 C2_HD void rhcrit_setup(real_t ztrpaus, RhCrit& r) {
@@ -353,23 +346,20 @@ C2_HD void rhcrit_setup(real_t ztrpaus, RhCrit& r) {
   real_t dq = d / RC(0.15);
   r.zrh2 = RC(0.35) + RC(0.14) * (dq * dq) + RC(0.04) * fmin(d, RC(0.0)) / RC(0.15);
   r.zdeta1 = RC(0.09) + RC(0.16) * (RC(0.4) - ztrpaus) / RC(0.3);
-  r.rzdeta1 = RC(1.0) / r.zdeta1;
 }
 
-template <bool P>
 C2_HD real_t rhcrit_level(const RhCrit& r, real_t ceta) {
   // cloudsc2.F90:391-399 (ZRH1 = ZRH3 = 1, ZDETA2 = 0.3)
   const real_t zdeta2 = RC(0.3);
-  constexpr bool RCP = !P && (C2_RHCRIT_RCP != 0);
   real_t zcrh2 = RC(1.0);
   if (ceta < r.zeta3) {
     zcrh2 = RC(1.0);
   } else if (ceta < (r.zeta3 + zdeta2)) {
-    zcrh2 = RC(1.0) + (r.zrh2 - RC(1.0)) * (RCP ? (ceta - r.zeta3) * (RC(1.0) / zdeta2) : (ceta - r.zeta3) / zdeta2);
+    zcrh2 = RC(1.0) + (r.zrh2 - RC(1.0)) * ((ceta - r.zeta3) / zdeta2);
   } else if (ceta < (RC(1.0) - r.zdeta1)) {
     zcrh2 = r.zrh2;
   } else {
-    zcrh2 = RC(1.0) + (r.zrh2 - RC(1.0)) * sqrt(RCP ? (RC(1.0) - ceta) * r.rzdeta1 : (RC(1.0) - ceta) / r.zdeta1);
+    zcrh2 = RC(1.0) + (r.zrh2 - RC(1.0)) * sqrt((RC(1.0) - ceta) / r.zdeta1);
   }
   return zcrh2;
 }
@@ -377,9 +367,6 @@ C2_HD real_t rhcrit_level(const RhCrit& r, real_t ceta) {
 template <bool PRECISE>
 C2_HD real_t ex(real_t x) { return PRECISE ? exp(x) : c2_exp(x); }
 
-#ifndef C2_SATUR_UNIFORM
-#define C2_SATUR_UNIFORM 0
-#endif
 // FOEALFA (src/common/include/fcttre.func.h:74-75)
 C2_HD real_t foealfa(ConstsP c, real_t t) {
   real_t x = (fmax(c->rtice, fmin(c->rtwat, t)) - c->rtice) * c->rtwat_rtice_r;
@@ -410,20 +397,10 @@ C2_HD real_t satur_point(ConstsP c, real_t pap, real_t t) {
     real_t rl, ri, rp;
     c2_rcp3(t - r4les, t - r4ies, pap, rl, ri, rp);
     real_t dt = t - rtt;
-    // both exps unconditionally per LANE: a lane-divergent skip of the zero-weight exp costs more (the constant block is
-    // re-fetched inside every branch) than the ~20 instructions it saves.  C2_SATUR_UNIFORM: skipped when NO lane of the wave
-    // needs it (all lanes at or below RTICE: no liquid part; all at or above RTWAT: no ice part) -- a scalar branch on a ballot,
-    // taken by whole waves on most levels of an atmosphere (cold aloft, warm below).  The skipped term has weight exactly 0, so
-    // the result keeps its bits.
-#if C2_SATUR_UNIFORM && defined(__HIP_DEVICE_COMPILE__)
-    zfoeewl = RC(0.0);
-    zfoeewi = RC(0.0);
-    if (__builtin_amdgcn_ballot_w64(zalfa > RC(0.0)) != 0) zfoeewl = r2es * c2_exp(r3les * dt * rl);
-    if (__builtin_amdgcn_ballot_w64(zalfa < RC(1.0)) != 0) zfoeewi = r2es * c2_exp(r3ies * dt * ri);
-#else
+    // both branches unconditionally: a lane-divergent skip of the zero-weight exp costs more (the constant block is
+    // re-fetched inside every branch) than the ~20 instructions it saves
     zfoeewl = r2es * c2_exp(r3les * dt * rl);
     zfoeewi = r2es * c2_exp(r3ies * dt * ri);
-#endif
     real_t zfoeew = zalfa * zfoeewl + (RC(1.0) - zalfa) * zfoeewi;
     zqs = zfoeew * rp;
     if (zqs > RC(0.5)) zqs = RC(0.5);
@@ -492,7 +469,10 @@ struct LevelTraj {
 // shipped configuration, and with the evaporation branch merely skipped at run time its live ranges still cost
 // ~60 VGPRs (one wave per SIMD less in the NL kernel).  With EVAP=false t.llo2 is a compile-time false, which also
 // removes the branch's TL and AD statements.
-template <bool P, bool EVAP>
+// LIN is `LPHYLIN .OR. LDRAIN1D` (cloudsc2.F90:349), true in every shipped configuration (the three mains force LPHYLIN=.true.,
+// dwarf_cloudsc.F90:107) and always for the trajectories of CLOUDSC2TL / CLOUDSC2AD, which have no other form; false selects the
+// FOEALFA / FOEEWM form of stage A (:365-369) in the NL sweep.
+template <bool P, bool EVAP, bool LIN = true>
 C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const LevelIn& x, Carry& cy,
                          LevelTraj& t, LevelOut& o) {
   const real_t zqmax = RC(0.5), zeps2 = RC(1.e-10);
@@ -537,7 +517,17 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
 
   // A. mixed phase and dqs/dT (cloudsc2.F90:350-375, LPHYLIN branch)
   t.cold = t.ztp2 < rtt;
-  {
+  if (!LIN) {
+    // ZFWAT = FOEALFA(T), ZFOEEW = FOEEWM(T) (cloudsc2.F90:366-367; fcttre.func.h:74-75,81-83); ZESDP is not clipped (:368)
+    const StageBlock kf = c2_block(&c->kf);
+    const real_t xa = (fmax(kf.v[KF_RTICE], fmin(kf.v[KF_RTWAT], t.ztp2)) - kf.v[KF_RTICE]) * kf.v[KF_RTWAT_RTICE_R];
+    t.zfwat = fmin(RC(1.0), xa * xa);
+    t.zcosh2r = RC(0.0);
+    const real_t dt = t.ztp2 - rtt;
+    const real_t el = ex<P>(quot<P>(k0.v[K0_R3LES] * dt, t.tm4l, rl));
+    const real_t ei = ex<P>(quot<P>(k0.v[K0_R3IES] * dt, t.tm4i, ri));
+    t.zfoeew = k0.v[K0_R2ES] * (t.zfwat * el + (RC(1.0) - t.zfwat) * ei);
+  } else {
     real_t z3es, z4es, r4;
     if (P) {
       real_t u = RC(0.17) * (t.ztp2 - k0.v[K0_RLPTRC]);
@@ -566,7 +556,7 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
   const real_t retv = k1.v[K1_RETV], rg = k1.v[K1_RG];
   {
     real_t zesdp1 = quot<P>(t.zfoeew, x.pap, rp);
-    t.esdp_clip = zesdp1 > zqmax;
+    t.esdp_clip = LIN && zesdp1 > zqmax;
     t.zesdp = t.esdp_clip ? zqmax : zesdp1;
     t.zfacw = quot<P>(k1.v[K1_R5LES], t.tm4l * t.tm4l, rl * rl);
     t.zfaci = quot<P>(k1.v[K1_R5IES], t.tm4i * t.tm4i, ri * ri);
@@ -588,7 +578,7 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
   }
 
   // B. critical relative humidity (cloudsc2.F90:384-407)
-  t.zcrh2 = rhcrit_level<P>(rh, k.ceta);
+  t.zcrh2 = rhcrit_level(rh, k.ceta);
   t.below_rtice = t.ztp2 < k1.v[K1_RTICE];
   t.zsupsat = t.below_rtice ? (RC(1.8) - RC(3.e-03) * t.ztp2) : RC(1.0);
   t.zqsat = x.qs * t.zsupsat;

@@ -49,7 +49,9 @@ typedef struct cloudsc2_params {
   double rclcrit, rkconv, rlmin, rpecons;                                      /* YOECLDP */
   double rlptrc;                                                               /* YOEPHLI */
   double rticecu, rtwat_rticecu_r;                                             /* YOETHF, dead branches only */
-  int lphylin;   /* must be 1: every reference main forces it (dwarf_cloudsc.F90:107) */
+  int lphylin;   /* YREPHLI%LPHYLIN: 1 in every reference main (dwarf_cloudsc.F90:107).  0 selects the FOEALFA / FOEEWM form of the NL
+                  * sweep's saturation pressure (cloudsc2.F90:349,365-369; unless ldrain1d); CLOUDSC2TL / CLOUDSC2AD and the driver's
+                  * SATUR call (cloudsc_driver_mod.F90:91: LDPHYLIN=.TRUE.) do not depend on it */
   int levapls2;  /* precipitation evaporation on/off (LEVAPLS2 .OR. LDRAIN1D, cloudsc2.F90:557) */
   int lregcl;    /* TL/AD regularisation (cloudsc2tl.F90:575,657,754,794,998) */
   int ldrain1d;

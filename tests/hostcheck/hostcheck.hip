@@ -22,7 +22,7 @@ static void hc_dispatch(unsigned f, long long gc, const A* a) {
 }
 template <unsigned F> struct HcNl {
   static void run(long long gc, const NlArgs* a) {
-    if constexpr (!((F & C2F_PERT) && (F & C2F_CKPT))) nl_column<F>(gc, a);
+    if constexpr (!(F & C2F_CKPT)) nl_column<F>(gc, a);
   }
 };
 // only the flag words the launchers can produce are instantiated (TL: QSAT|PRECISE|EVAP|TRAJ|OFF32, AD: no TRAJ)
@@ -110,8 +110,8 @@ int hostcheck_nl(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev
   hc_in(*in, a.s, a.in); hc_out(*out, a.s, a.out);
   a.zero_plane = zero_plane.ptr; a.zero_stride = zero_plane.block_stride; a.lam = lam; a.ckpt = nullptr;
   unsigned f = (in->qsat.ptr ? C2F_QSAT : 0u) | (lam != 0.0 ? C2F_PERT : 0u) | (g_hc_precise ? C2F_PRECISE : 0u) |
-               (a.c.evap ? C2F_EVAP : 0u) | (g_hc_off32 ? C2F_OFF32 : 0u);
-  for (long long gc = 0; gc < a.g.ncols_pad; ++gc) hc_dispatch<HcNl, 64>(f, gc, &a);
+               (a.c.evap ? C2F_EVAP : 0u) | (g_hc_off32 ? C2F_OFF32 : 0u) | ((!prm->lphylin && !prm->ldrain1d) ? C2F_NOLIN : 0u);
+  for (long long gc = 0; gc < a.g.ncols_pad; ++gc) hc_dispatch<HcNl, 128>(f, gc, &a);
   return 0;
 }
 

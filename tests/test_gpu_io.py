@@ -105,7 +105,11 @@ def test_device_tiler_and_validator_against_the_reference_modules(nproma, ngptot
     for (label, ndim, stats), line, (name, f) in zip(rows, lines, fields.items()):
         blocked_ref = reflib.expand(ref_tab[name][..., sl], nproma, ngptot)
         want = reflib.validate(label, blocked_ref, f, ngptot, ngptotg)
-        assert line[:88] == want[:88], (label, line, want)  # name, nD-option, MinValue, MaxValue, AbsMaxErr
+        # name, nD-option, MinValue, MaxValue, AbsMaxErr: the same characters -- except the SIGN of a zero extreme of a field that holds
+        # both zeros (the enthalpy fluxes: -0 at the model top, cloudsc2.F90:732-733, +0 in the padding), which depends on the order
+        # of the comparisons in MAXVAL / MAX and is the compiler's choice in the reference too
+        unsigned = lambda t: t.replace("-0.0000000000000E+00", " 0.0000000000000E+00")  # noqa: E731
+        assert unsigned(line[:88]) == unsigned(want[:88]), (label, line, want)
         for a, b in ((line[88:109], want[88:109]), (line[109:130], want[109:130])):
             assert abs(_fortran_real(a.strip()) - _fortran_real(b.strip())) <= 1e-12 * abs(_fortran_real(b.strip())), (label, a, b)
         assert line[130:] == want[130:], (label, line, want)  # the `!!!!` flag

@@ -609,9 +609,28 @@ def test_invalid_arguments_fail_loudly():
     with pytest.raises(c2.Cloudsc2Error) as e:
         c2.run_state(bad, st, "nl")
     assert e.value.code == B.CLOUDSC2_EINVAL
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_nl_without_lphylin(mode):
+    """YREPHLI%LPHYLIN=.false. -- the FOEALFA / FOEEWM form of the NL sweep's saturation pressure (cloudsc2.F90:349,365-369), off in
+    every reference main -- against the reference Fortran with the same switch; SATUR stays in its LDPHYLIN form as in the driver
+    (cloudsc_driver_mod.F90:91)."""
+    tab = c2.random_table(137, 100, seed=17)
+    prm = c2.default_params(c2.ceta_from_table(tab))
     prm.lphylin = 0
-    with pytest.raises(c2.Cloudsc2Error):
-        c2.run_state(prm, st, "nl")
+    prm.math_mode = mode
+    st = c2.state_from_table(tab, 64, 300)
+    chk = checker()
+    set_lib_params(chk, prm)
+    want = ref_nl_state(chk, st, prm)
+    got = st.copy()
+    c2.run_state(prm, got, "nl")
+    assert_outputs_close(want, got, NL_TOL if mode == 2 else 10 * NL_TOL)
+    prm.lphylin = 1
+    lin = st.copy()
+    c2.run_state(prm, lin, "nl")
+    assert not np.array_equal(lin.PA, got.PA)  # the switch is read
 
 
 def _run_fortran(exe, *args, cwd=None, env=None):

@@ -212,6 +212,37 @@ def test_tl_ad_columns(oracle, flags, nlev):
         assert np.max(np.abs(n1 - n2 - n2s) / np.abs(n1)) < 1e4 * 2.2e-16
 
 
+@pytest.mark.parametrize("ldrain1d", [False, True])
+def test_nl_without_lphylin(oracle, ldrain1d):
+    """YREPHLI%LPHYLIN=.false. (off in every reference main): the FOEALFA / FOEEWM form of stage A (cloudsc2.F90:365-369), unless
+    LDRAIN1D switches the linearised form back on (:349)."""
+    tab = c2.random_table(137, 40, seed=9)
+    prm = make_params(tab, ldrain1d=ldrain1d)
+    prm.lphylin = 0
+    set_lib_params(oracle, prm)
+    nproma, ngptot = 16, 40
+    st = c2.state_from_table(tab, nproma, ngptot)
+    got = st.copy()
+    i, o = host_traj_blocks(got)
+    assert hostcheck().hostcheck_nl(C.byref(prm), st.ptsphy, nproma, st.nlev, ngptot, C.byref(i), C.byref(o), B.Field(), 0.0) == 0
+    lin = st.copy()
+    prm_lin = make_params(tab, ldrain1d=ldrain1d)
+    il, ol = host_traj_blocks(lin)
+    assert hostcheck().hostcheck_nl(C.byref(prm_lin), st.ptsphy, nproma, st.nlev, ngptot, C.byref(il), C.byref(ol), B.Field(), 0.0) == 0
+    differs = False
+    for ibl in range(st.nblocks):
+        icend = min(nproma, ngptot - ibl * nproma)
+        qs = oracle.satur(np.ascontiguousarray(st.PAP[ibl]), np.ascontiguousarray(st.PT[ibl]), kfdia=icend)
+        inp = refcall.block_inputs(st, ibl, qs)
+        for a in inp.values():
+            a[:, icend:] = 1.0
+        want = oracle.cloudsc2(st.ptsphy, inp, kfdia=icend, ldrain1d=ldrain1d)
+        for n, a in refcall.state_outputs_block(got, ibl).items():
+            assert relerr(want[n][:, :icend], a[:, :icend]) <= TOL, (n, ibl)
+            differs |= not np.array_equal(a[:, :icend], refcall.state_outputs_block(lin, ibl)[n][:, :icend])
+    assert differs != ldrain1d  # the switch changes the results -- except under LDRAIN1D, where it is not read
+
+
 def test_perturbed_nl_matches_explicit_perturbation(oracle):
     """pert_lambda of cloudsc2_nl_launch = the Taylor test's x + lambda*(0.01 x) (cloudsc_driver_tl_mod.F90:200-215)."""
     tab = c2.synthetic_table()

@@ -119,6 +119,28 @@ def test_oracle_equals_reference(oracle, flags):
 
 
 @pytest.mark.skipif(not refcall.have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+def test_oracle_equals_reference_without_lphylin(oracle):
+    """YREPHLI%LPHYLIN=.false. (cloudsc2.F90:365-369, FOEALFA / FOEEWM): the NL restatement against the reference with the switch
+    off -- bit for bit like the shipped configuration -- and the switch changes the results."""
+    tab = c2.random_table(137, 48, seed=23)
+    prm = make_params(tab)
+    ref = refcall.RefLib()
+    set_lib_params(ref, prm)
+    st, inp = table_inputs(ref, tab, 48)
+    lin = ref.cloudsc2(st.ptsphy, inp)
+    prm.lphylin = 0
+    set_lib_params(ref, prm)
+    set_lib_params(oracle, prm)
+    a, b = ref.cloudsc2(st.ptsphy, inp), oracle.cloudsc2(st.ptsphy, inp)
+    for n in a:
+        assert relerr(a[n], b[n]) <= ORACLE_TOL, ("nl", n)
+    assert not np.array_equal(a["tent"], lin["tent"])
+    prm.lphylin = 1
+    set_lib_params(ref, prm)  # the reference library's module state is process-wide: leave it as the other tests expect it
+    set_lib_params(oracle, prm)
+
+
+@pytest.mark.skipif(not refcall.have_ref(), reason="oracle/_ref not built (needs /root/reference)")
 def test_oracle_driver_equals_reference_driver(oracle):
     """The OpenMP block loop used for the CPU baseline when the reference build cannot travel."""
     import ctypes as C
