@@ -87,7 +87,7 @@ def test_device_tiler_and_validator_against_the_reference_modules(nproma, ngptot
     prm = c2.default_params(c2.ceta_from_table(tab))
     ds.nl(prm)
     torch.cuda.synchronize()
-    st = ds.download(c2.state_from_table(tab, nproma, ngptot))
+    st = ds.download(c2.state_from_table(tab, nproma, ngptot, col0=start))  # (start + g < KLON for a rank slice: the same columns)
     cols = (start + np.arange(min(100, ngptot)) % (100 if period is None else period)) % 100
     rng = np.random.default_rng(3)
     fields = {"PLUDE": st.PLUDE, "PCOVPTOT": st.PCOVPTOT, "PFPLSL": st.PFPLSL, "PFPLSN": st.PFPLSN, "PFHPSL": st.PFHPSL,

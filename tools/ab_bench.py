@@ -23,6 +23,6 @@ for r in range(rounds):
                 d = json.loads(out.strip().split("\n")[-1])
                 res.setdefault((k, n, lib), []).append(d["roofline"]["kernel_ms_avg"])
 for (k, n, lib), v in sorted(res.items()):
-    bpc = {"nl": 28536, "tl": 57072, "ad": 87800}[k]
+    bpc = {"nl": 28536, "tl": 57072, "ad": 85608}[k]
     med = statistics.median(v)
     print(f"{k} {n:>8} {lib:40s} median {med:7.3f} ms  frac {bpc * int(n) / (med * 1e-3) / 8e12:5.3f}   all {[round(x, 3) for x in v]}")

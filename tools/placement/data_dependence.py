@@ -8,7 +8,7 @@ import sys
 
 if os.environ.get("DD_PLACE") != "1":  # DD_PLACE=1: through the placing allocator (one state, e.g. at 1 048 576 columns)
     os.environ["CLOUDSC2_PLACE"] = "0"
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 

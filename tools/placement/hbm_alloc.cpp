@@ -1,6 +1,6 @@
-// hbm_alloc.cpp -- is the fast / slow write class of tools/hbm_probe.cpp a property of the ALLOCATION?
+// hbm_alloc.cpp -- is the fast / slow write class of tools/placement/hbm_probe.cpp a property of the ALLOCATION?
 //
-// tools/hbm_map.cpp found no slow place anywhere inside one 256 GiB allocation, while 150 separate 1.4 GB allocations
+// tools/placement/hbm_map.cpp found no slow place anywhere inside one 256 GiB allocation, while 150 separate 1.4 GB allocations
 // fall into two classes.  This program allocates series of buffers in different ways and times the same work on each
 // (a 16-byte-per-lane fill and the NL-shaped strided write over the first GiB), printing the exact addresses:
 //   series A: N x hipMalloc(1 402 880 000 + 4 MiB)   (the odd size of a 160 000-column B_LOC)
@@ -8,7 +8,7 @@
 //   series C: N windows of 1.5 GiB inside ONE hipMalloc
 //   series D: N x (hipMemAddressReserve aligned to 1 GiB + hipMemCreate + hipMemMap), 1.5 GiB each
 //   series E: N x hipMalloc(6.4 GB)                  (a whole state arena)
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o hbm_alloc tools/hbm_alloc.cpp
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o hbm_alloc tools/placement/hbm_alloc.cpp
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdint>

@@ -2,7 +2,7 @@
 // allocated alternately so that all four kinds are spread over the same parts of the HBM:
 //   a: hipMalloc(1.4 GB)                       b: reserve + 3 x hipMemCreate(512 MiB)
 //   c: reserve + 1 x hipMemCreate(1.4 GB)      d: reserve + 22 x hipMemCreate(64 MiB)
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o hbm_alloc2 tools/hbm_alloc2.cpp
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o hbm_alloc2 tools/placement/hbm_alloc2.cpp
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdint>

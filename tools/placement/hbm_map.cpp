@@ -1,13 +1,13 @@
 // hbm_map.cpp -- map of the write (and read) bandwidth of one large allocation, window by window, on an MI355X.
 //
-// tools/hbm_probe.cpp showed that EVERY write pattern -- the NL sweep's strided plane writes as well as a plain
+// tools/placement/hbm_probe.cpp showed that EVERY write pattern -- the NL sweep's strided plane writes as well as a plain
 // contiguous 16-byte-per-lane fill -- runs 10-20 % slower on some allocations than on others, while reads do not care.
 // This program asks where those places are and who pays:
 //   1. one allocation of G GiB, filled window by window (W MiB each): GB/s per window  -> the map, and its granularity;
 //   2. on the fastest and the slowest window: fills issued from ONE XCD at a time (workgroup id mod 8), streaming reads,
 //      and fills of the two windows concurrently;
 //   3. mode "pmc": ten fills of the fastest window (kernel fill_tag<2>) and ten of the slowest (fill_tag<1>) for rocprofv3.
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o hbm_map tools/hbm_map.cpp
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o hbm_map tools/placement/hbm_map.cpp
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>

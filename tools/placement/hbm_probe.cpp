@@ -9,7 +9,7 @@
 //   mode "slices"  : the slowest buffer cut in 8 slices of blocks: is the slowness local to a part of it?
 //   mode "pmc"     : ten launches on the fastest (kernel nl_writes<2>) and ten on the slowest buffer (nl_writes<1>),
 //                    for rocprofv3 --pmc passes (per-instance TCC counters)
-// build: hipcc --offload-arch=gfx950 -O3 -o hbm_probe tools/hbm_probe.cpp
+// build: hipcc --offload-arch=gfx950 -O3 -o hbm_probe tools/placement/hbm_probe.cpp
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>

@@ -1,7 +1,7 @@
 // hbm_state.cpp -- is a buffer's write class intrinsic, or does it depend on what else is allocated?
 // Buffer 0 (1.4 GB, hipMalloc) is timed alone, then again after 20, 60 and 150 further buffers exist, then after all but the
 // fastest of them have been freed.  Same kernel (the NL sweep's plane writes, 1250 blocks) every time.
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o hbm_state tools/hbm_state.cpp
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o hbm_state tools/placement/hbm_state.cpp
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>

@@ -5,7 +5,7 @@
 //   2. the same chunks mapped in REVERSE order into the same slots: does the class follow the chunk or the slot?
 //   3. the fastest K and the slowest K chunks mapped contiguously as two arenas: the NL sweep's strided plane writes and a
 //      contiguous fill on each -- can a write-fast arena be composed from probed chunks?
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o hbm_vmm tools/hbm_vmm.cpp
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o hbm_vmm tools/placement/hbm_vmm.cpp
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>

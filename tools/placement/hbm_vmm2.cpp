@@ -4,7 +4,7 @@
 //   consecutive : chunks i .. i+m-1                     (what one large allocation gets)
 //   spread      : chunks i, i+N/m, i+2N/m, ...          (taken from all over the memory)
 //   pairs       : half of the arena from region a, half from region b, alternating, for all pairs of R regions
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o hbm_vmm2 tools/hbm_vmm2.cpp
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o hbm_vmm2 tools/placement/hbm_vmm2.cpp
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdint>

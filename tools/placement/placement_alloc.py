@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """The real kernels on states whose arrays come (a) from torch's allocator = plain hipMalloc, (b) from
 cloudsc2_device_malloc = address ranges backed by hipMemCreate chunks.  N states of each kind, allocated alternately, each
-timed; no placement search.    python tools/placement_alloc.py [N [NGPTOT [KERNELS]]]"""
+timed; no placement search.    python tools/placement/placement_alloc.py [N [NGPTOT [KERNELS]]]"""
 import os
 import statistics as st
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa: E402
 
 import dwarf_p_cloudsc2_tl_ad_amd as c2  # noqa: E402

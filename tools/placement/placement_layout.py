@@ -3,11 +3,11 @@
 timed with the real NL kernel (a) writing its tendencies into B_LOC as the reference lays it out (5 of 8 planes,
 137 KiB every 1096 KiB), (b) writing them into five plane-major arrays (NPROMA,NLEV,NBLOCKS) allocated next to the
 state, (c) additionally reading the four PGTEN* planes from plane-major arrays instead of B_CML.
-    python tools/placement_layout.py [N [NGPTOT [KERNEL]]]"""
+    python tools/placement/placement_layout.py [N [NGPTOT [KERNEL]]]"""
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa: E402
 
 import dwarf_p_cloudsc2_tl_ad_amd as c2  # noqa: E402

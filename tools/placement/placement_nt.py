@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Fast and slow placements under other builds of the library (e.g. without non-temporal stores), same allocations:
-python tools/placement_nt.py N lib1.so lib2.so ..."""
+python tools/placement/placement_nt.py N lib1.so lib2.so ..."""
 import ctypes as C
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa: E402
 
 import dwarf_p_cloudsc2_tl_ad_amd as c2  # noqa: E402

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Does the placement of the state in HBM change the NL kernel's time?  Several states are allocated side by side in
-one process (so they occupy different physical memory) and each is timed: python tools/placement_probe.py [NGPTOT [N]]"""
+one process (so they occupy different physical memory) and each is timed: python tools/placement/placement_probe.py [NGPTOT [N]]"""
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa: E402
 
 import dwarf_p_cloudsc2_tl_ad_amd as c2  # noqa: E402
