@@ -359,25 +359,32 @@ __device__ __forceinline__ double wave_max(double v) {
 struct TenPtrs { const real_t* p[10]; long long stride[10]; int nlevx[10]; };
 
 // `nproma` is the block of the STATISTIC (the caller's NPROMA: ERROR_NORM sums over one NPROMA block); the arrays are blocked by
-// `nproma_phys` (the same, except for resident states the library blocks differently from the caller).
+// `nproma_phys` (the same, except for resident states the library blocks differently from the caller).  The 256 threads of a
+// workgroup are laid over the block as (column, level slice): all of them work whatever NPROMA is -- with one thread per column
+// only, the README's NPROMA 32 left 7 of 8 lanes idle and the ten sums launches cost more than the twelve sweeps they follow.
 __global__ void __launch_bounds__(256) taylor_sums_kernel(int nproma, int nproma_phys, int nlev, int ngptot, TenPtrs f, TenPtrs f5,
                                                           TenPtrs tl, double lambda, double* sums) {
   (void)nlev;
   const int ibl = blockIdx.x;
   const int icend = min(nproma, ngptot - ibl * nproma);
+  const int ncolt = min(nproma, (int)blockDim.x);    // threads along the columns
+  const int nslice = (int)blockDim.x / ncolt;        // level slices (>= 1)
+  const int jl0 = threadIdx.x % ncolt, slice = threadIdx.x / ncolt;
   __shared__ double red[2][4];
   for (int fi = 0; fi < 10; ++fi) {
     double s0 = 0.0, s1 = 0.0;
     const int nl = f.nlevx[fi];
-    for (int jl = threadIdx.x; jl < icend; jl += blockDim.x) {
-      const long long g = (long long)ibl * nproma + jl, pb = g / nproma_phys, pj = g - pb * nproma_phys;
-      const real_t* a = f.p[fi] + pb * f.stride[fi] + pj;
-      const real_t* b = f5.p[fi] + pb * f5.stride[fi] + pj;
-      const real_t* t = tl.p[fi] + pb * tl.stride[fi] + pj;
-      for (int jk = 0; jk < nl; ++jk) {
-        long long d = (long long)jk * nproma_phys;
-        s0 += a[d] - b[d];
-        s1 += t[d] * lambda;
+    if (slice < nslice) {
+      for (int jl = jl0; jl < icend; jl += ncolt) {
+        const long long g = (long long)ibl * nproma + jl, pb = g / nproma_phys, pj = g - pb * nproma_phys;
+        const real_t* a = f.p[fi] + pb * f.stride[fi] + pj;
+        const real_t* b = f5.p[fi] + pb * f5.stride[fi] + pj;
+        const real_t* t = tl.p[fi] + pb * tl.stride[fi] + pj;
+        for (int jk = slice; jk < nl; jk += nslice) {
+          long long d = (long long)jk * nproma_phys;
+          s0 += a[d] - b[d];
+          s1 += t[d] * lambda;
+        }
       }
     }
     s0 = wave_sum(s0);

@@ -43,7 +43,9 @@ def test_two_ranks_split_the_columns_and_reduce_the_statistics(tmp_path):
     assert "NUMPROC=1," in err1 and "NUMPROC=2," in err2
     assert "NGPBLKS=24" in err2                      # 1500 columns per rank (dwarf_cloudsc.F90:64-69) in blocks of 64
     assert err2.count("NUMPROC=2,") == 1             # rank 0 alone prints the header, and one table row per rank
-    assert ": rank 0" in err2 and ": rank 1" in err2
+    # the reference's timing table (timer_mod.F90:124-171): one worker row and one TOTAL row per rank, one grand TOTAL
+    assert "@ rank#0:core#" in err2 and "@ rank#1:core#" in err2 and ": TOTAL @ rank#0" in err2 and ": TOTAL @ rank#1" in err2
+    assert "      2 x 1" in err2 and "Time(msec)" in err2
     a, b = _summary(one), _summary(two)
     for k in a:  # min and max exactly; the sequential sums of 4e5 terms are added in another order
         assert a[k][0] == b[k][0] and a[k][1] == b[k][1], k

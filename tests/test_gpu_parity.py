@@ -630,7 +630,7 @@ def test_nl_without_lphylin(mode):
     prm.lphylin = 1
     lin = st.copy()
     c2.run_state(prm, lin, "nl")
-    assert not np.array_equal(lin.PA, got.PA)  # the switch is read
+    assert not np.array_equal(lin.B_LOC, got.B_LOC)  # the switch is read
 
 
 def _run_fortran(exe, *args, cwd=None, env=None):

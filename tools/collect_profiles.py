@@ -38,4 +38,14 @@ for k in ("nl", "tl", "ad"):
         out[f"{k}_{n}"] = {"ms_per_step": d["ms_per_step"], "value": d["value"], "dtype": d["dtype"], "roofline": d["roofline"],
                            "placement": d["config"]["placement"]}
         print(prefix, k, n, round(d["roofline"]["kernel_ms_avg"], 3), "ms", round(100 * d["roofline"]["frac"], 1), "%", "%.3e" % d["value"])
+for form in ("adassign", "adreverse", "adreverseassign"):  # the adjoint's other forms (tools/evidence.sh)
+    for n in (16384, 160000, 1048576):
+        f = os.path.join(src, f"bench_{form}_{n}.json")
+        if os.path.exists(f) and os.path.getsize(f):
+            d = json.load(open(f))
+            out[f"{form}_{n}"] = {"ms_per_step": d["ms_per_step"], "value": d["value"], "dtype": d["dtype"], "roofline": d["roofline"]}
+for n in (16384, 160000):
+    f = os.path.join(src, f"symmetry_{n}.json")
+    if os.path.exists(f) and os.path.getsize(f):
+        out[f"adjoint_test_{n}"] = json.load(open(f))
 json.dump(out, open(os.path.join(dst, f"{prefix}_bench_all_kernels.json"), "w"), indent=1)

@@ -27,3 +27,9 @@ for k in nl tl ad; do for n in 160000 1048576; do
   timeout -k 10 300 python bench.py --kernel $k --ngptot $n --steps 30 --warmup 3 --no-cpu-baseline --no-companions > $out/bench_${k}_$n.json 2>/dev/null
   python -c "import json; d=json.load(open('$out/bench_${k}_$n.json')); print('$k $n', round(d['ms_per_step'],3), '%.3e'%d['value'], round(d['roofline']['frac'],3))"
 done; done
+# the adjoint's other forms: assign (x = A^T y), the reverse sweep alone, and both (the AD leg of the adjoint test)
+for n in 16384 160000 1048576; do for form in "adassign:--ad-assign" "adreverse:--ad-sweep reverse" "adreverseassign:--ad-sweep reverse --ad-assign"; do
+  timeout -k 10 300 python bench.py --kernel ad ${form#*:} --ngptot $n --steps 30 --warmup 3 --no-cpu-baseline --no-companions > $out/bench_${form%%:*}_$n.json 2>/dev/null
+  python -c "import json; d=json.load(open('$out/bench_${form%%:*}_$n.json')); r=d['roofline']; print('${form%%:*} $n', round(r['kernel_ms_avg'],3), r['bytes_per_column'], round(r['frac'],3))"
+done; done
+for n in 16384 160000; do timeout -k 10 300 python tools/symmetry_timing.py $n > $out/symmetry_$n.json 2>/dev/null && cat $out/symmetry_$n.json; done

@@ -9,7 +9,8 @@ for rep in 1 2; do
 for own in "" 0; do
   for k in nl tl ad; do
     for np in 32 100 128; do
-      CLOUDSC2_STATE_NPROMA=$own CLOUDSC2_RESIDENT=1 timeout -k 10 300 $bld/dwarf-cloudsc2-$k 1 160000 $np > run.log 2> run.err || { echo "FAILED $k $np"; tail -5 run.err; exit 1; }
+      if [ -z "$own" ]; then unset CLOUDSC2_STATE_NPROMA; else export CLOUDSC2_STATE_NPROMA=$own; fi
+      CLOUDSC2_RESIDENT=1 timeout -k 10 300 $bld/dwarf-cloudsc2-$k 1 160000 $np > run.log 2> run.err || { echo "FAILED $k $np"; tail -5 run.err; exit 1; }
       ms=$(grep "GPU kernel" run.err | head -1 | awk '{print $3}')
       verdict=$(grep -h -i "TEST PASSED\|TEST OK\|TEST FAILED" run.log run.err | head -1 | cut -c1-60)
       echo "dwarf-cloudsc2-$k 1 160000 $np resident, device blocking ${own:-default}: $ms ms  $verdict"
