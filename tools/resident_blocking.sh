@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round 3, session c: GPU suite; the Fortran mains on the resident state at the caller's NPROMA 32 / 100 / 128 (device arrays blocked
+# GPU suite; the Fortran mains on the resident state at the caller's NPROMA 32 / 100 / 128 (device arrays blocked
 # by the library), fresh process per run; with CLOUDSC2_STATE_NPROMA=0 (device arrays in the caller's blocking) for comparison.
-tag=${1:-r03_c}; out=$PWD/gpurun_out/$tag; mkdir -p $out; bld=$PWD/dwarf_p_cloudsc2_tl_ad_amd/fortran/build
+tag=${1:-resident}; out=$PWD/gpurun_out/$tag; mkdir -p $out; bld=$PWD/dwarf_p_cloudsc2_tl_ad_amd/fortran/build
 export TMPDIR=/tmp
 timeout -k 10 900 python -m pytest tests -m gpu -q --durations=6 > $out/pytest_gpu.log 2>&1; tail -12 $out/pytest_gpu.log
 cd $out
