@@ -26,6 +26,7 @@ struct Geom {
   int nproma, nlev, ngptot;
   long long ncols_pad;  // NBLOCKS*NPROMA
   int kb0, kb1;         // tropopause band [kb0,kb1): levels that can satisfy 0.1 < CETA < 0.4 (cloudsc2.F90:320)
+  int fair;             // NL: the waves of a SIMD yield to each other by progress (progress_priority); set by the launcher
 };
 
 // Fields are grouped by the stride between NPROMA blocks.  `full` = (NPROMA,NLEV,NBLOCKS) arrays,
@@ -316,6 +317,33 @@ C2_HD void satur_column(long long gcol, SaturArgsP a) {
   }
 }
 
+// Waves that share a SIMD are served oldest first: of the three NL waves on a SIMD the oldest runs as if alone and finishes a
+// 160 000-column launch after 540 us, the second after 670, the youngest after 800 (tools/wave_times.py,
+// profiles/r03_wave_times.txt) -- and the launch ends with its youngest waves, each alone on its SIMD and latency-bound, on a
+// machine that has been half empty for 250 us.  With `fair` a wave's issue priority FALLS as it advances (s_setprio 3, 2, 1, 0,
+// 3, ... per group of C2_PRIO_GROUP levels), so a wave that has got ahead of its SIMD's other waves yields to them until they
+// have caught up: the waves of a SIMD stay within about one group of each other and finish together, whatever their age and
+// wherever the dispatcher put them.  It pays where a launch is ONE partial round of waves, i.e. the SIMDs carry unequal numbers
+// of them (160 000 columns: 2500 waves on 1024 SIMDs, 2 or 3 each: -5 %); with equal loads or several rounds the age order is
+// as good or better (waves of different age are naturally staggered), so the launcher sets it by launch size (nl launch).
+#ifndef C2_PRIO_GROUP
+#define C2_PRIO_GROUP 8
+#endif
+C2_HD void progress_priority(int jk, int fair) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (fair && jk % C2_PRIO_GROUP == 0) {
+    switch ((jk / C2_PRIO_GROUP) & 3) {  // (wave-uniform: scalar branches; s_setprio takes an immediate)
+      case 0: __builtin_amdgcn_s_setprio(3); break;
+      case 1: __builtin_amdgcn_s_setprio(2); break;
+      case 2: __builtin_amdgcn_s_setprio(1); break;
+      default: __builtin_amdgcn_s_setprio(0); break;
+    }
+  }
+#else
+  (void)jk; (void)fair;
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // NL: SATUR (optionally fused) + CLOUDSC2 for one column
 // ---------------------------------------------------------------------------------------------------------
@@ -331,7 +359,7 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
   static_assert(LIN || !CKPT, "CLOUDSC2AD's trajectory has the LPHYLIN form only");
   LaneOff o; bool active;
   if (!lane_setup(&a->g, &a->s, gcol, o, active)) return;
-  const int nlev = a->g.nlev, nproma = a->g.nproma;
+  const int nlev = a->g.nlev, nproma = a->g.nproma, fair = a->g.fair;
   const real_t lam = PERT ? a->lam : RC(0.0);
   real_t* zero_plane = a->zero_plane;
   long long ozero = 0;
@@ -382,6 +410,7 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
   // one level: `cur` holds the raw inputs of level jk (requested one level ago), `nxt` receives those of level jk+1
   auto step = [&](int jk, RawLevel& cur, RawLevel& nxt) {
     const bool last = (jk == nlev - 1);
+    progress_priority(jk, fair);
     NlArgsP ap = a;  // field pointers are re-read from the kernel-argument segment every level (transient SGPRs);
     C2_LAUNDER(ap);  // the physical constants stay resident
     // request everything level jk+1 needs now; nothing below touches `nxt` before the end of this level, so the
@@ -416,7 +445,10 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
     paph_k = cur.paph_k1;
   };
 
-  // (two levels of look-ahead with three register sets in rotation need 208 VGPRs, i.e. two waves per SIMD: 0.93 instead of 0.81 ms
+  // (round 3, with the waves of a SIMD kept abreast by progress_priority: a third register set for two levels of look-ahead -- 165
+  // VGPRs, still three waves per SIMD -- 0.790 against 0.784 ms at 160 000 columns and 4.98 against 4.91 at 1 M: the latency a
+  // deeper look-ahead would hide is not what is left.  Earlier:
+  // two levels of look-ahead with three register sets in rotation need 208 VGPRs, i.e. two waves per SIMD: 0.93 instead of 0.81 ms
   // at 160 000 columns, equal at 1 M -- profiles/r02_ab_experiments.txt; with three waves it spills 148 bytes per lane.  TOUCHING the
   // rows of level jk+2 instead -- one plain 32-bit load per lane and plane, 16 dwords held for a level, 167 VGPRs, no spill -- so that
   // the lines are in L2 / the Infinity Cache when the real load comes: 0.92 instead of 0.82 ms, 5.94 instead of 4.90 ms at 1 M; the
@@ -443,7 +475,7 @@ C2_HD void tl_column(long long gcol, TlArgsP a) {
   if (!lane_setup(&a->g, &a->s, gcol, o, active)) return;
   lane_setup(&a->g, &a->sp, gcol, op, active);
   if (!active) return;
-  const int nlev = a->g.nlev, nproma = a->g.nproma;
+  const int nlev = a->g.nlev, nproma = a->g.nproma, fair = a->g.fair;
   LevelTabP tab = (LevelTabP)a->tab;
   ConstsP c = C2_CONSTS(a);
   InPtrsP in = &a->in, din = &a->din;
@@ -476,6 +508,7 @@ C2_HD void tl_column(long long gcol, TlArgsP a) {
   // look-ahead 3 % slower at 160 000 columns and equal at 1 M: the full level of distance is what hides HBM latency here.
   for (int jk = 0; jk < nlev; ++jk) {
     const bool last = (jk == nlev - 1);
+    progress_priority(jk, fair);  // (set for the fp32 variants that run three waves per SIMD only, see cloudsc2_tl_launch)
     TlArgsP ap = a;
     C2_LAUNDER(ap);
     in = &ap->in; din = &ap->din;

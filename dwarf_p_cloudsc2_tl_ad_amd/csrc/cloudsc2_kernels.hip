@@ -170,9 +170,26 @@ __global__ void __launch_bounds__(kBlock) satur_kernel(SaturArgs args) {
 
 // The NL variants without the evaporation branch fit 168 VGPRs (3 waves per SIMD) even with the two-level-deep
 // prefetch; asking for it keeps the allocator from spending a few registers too many.  The others take what they need.
+// -DC2_WAVE_TIMES (diagnostic build, tools/wave_times.py): every wave of the NL kernel logs when it started and ended (the 100 MHz
+// constant clock) and where it ran (HW_ID, XCC_ID) -- how evenly a launch's waves start, progress and finish.
+#ifdef C2_WAVE_TIMES
+__device__ unsigned long long* g_wave_log = nullptr;  // [wave][4]: start, end, HW_ID, XCC_ID
+#define C2_WAVE_LOG_BEGIN const unsigned long long c2_t0 = __builtin_amdgcn_s_memrealtime();
+#define C2_WAVE_LOG_END                                                                                         \
+  if (g_wave_log && (threadIdx.x & 63) == 0) {                                                                  \
+    unsigned long long* e = g_wave_log + 4 * (((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);         \
+    e[0] = c2_t0; e[1] = __builtin_amdgcn_s_memrealtime();                                                     \
+    e[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4); e[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);        \
+  }
+#else
+#define C2_WAVE_LOG_BEGIN
+#define C2_WAVE_LOG_END
+#endif
 template <unsigned F>
 __global__ void __launch_bounds__(kBlock, (C2_NL_WAVES > 0) ? C2_NL_WAVES : ((F & C2F_EVAP) ? 1 : 3)) nl_kernel(NlArgs args) {
+  C2_KERNEL_BODY(C2_WAVE_LOG_BEGIN);
   C2_KERNEL_BODY((nl_column<F>(global_column(), kernarg<NlArgs>())));
+  C2_KERNEL_BODY(C2_WAVE_LOG_END);
 }
 
 // fp32 only: the TL variants with 32-bit offsets and without the evaporation branch need 173 VGPRs; held to 168 (3 waves
@@ -503,8 +520,27 @@ int check_geom(const cloudsc2_params* prm, int nproma, int nlev, int ngptot, Geo
   if (!device_ok()) return fail(CLOUDSC2_ENODEVICE, "no HIP device available (this library has no CPU path)");
   long long nblocks = ((long long)ngptot + nproma - 1) / nproma;
   g.nproma = nproma; g.nlev = nlev; g.ngptot = ngptot; g.ncols_pad = nblocks * nproma;
-  g.kb0 = 0; g.kb1 = 0;
+  g.kb0 = 0; g.kb1 = 0; g.fair = 0;
   return 0;
+}
+
+// Should the waves of this NL launch yield to each other by progress (cloudsc2_column.hpp: progress_priority)?  Yes when the launch
+// is ONE round of waves: no more waves than the device holds at the NL kernel's three per SIMD.  Measured
+// (profiles/r03_wave_times.txt): 100 000 ... 190 000 columns -1 ... -4 % (160 000: 0.815 -> 0.783 ms), 65 536 -3 %, 196 608
+// (exactly 3 per SIMD) +-1 %; with more than one round the age order is better (262 144 columns +4 %, 1 M +2 %): off there.
+// CLOUDSC2_FAIR=0|1 forces it (measurements only).
+int nl_fair(long long ncols_pad, bool evap) {
+  static const char* e = getenv("CLOUDSC2_FAIR");
+  if (e && *e) return atoi(e) != 0;
+  if (evap) return 0;  // one wave per SIMD: nobody to yield to
+  static int simds = 0;
+  if (!simds) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) simds = 4 * cus;
+    else simds = 1024;
+  }
+  const long long waves = (ncols_pad + 63) / 64, slots = 3LL * simds;
+  return waves <= slots;
 }
 
 // 32-bit byte offsets (C2F_OFF32) are usable when every buffer the sweep touches is smaller than 4 GiB
@@ -543,6 +579,26 @@ int cloudsc2_current_device(void) {
   return dev;
 }
 int cloudsc2_real_bytes(void) { return (int)sizeof(cloudsc2_real); }
+
+#ifdef C2_WAVE_TIMES
+// diagnostic build only: host_buf == NULL: (re)allocate the log for `nwaves` waves and arm it; else: copy it back (4 x u64 per wave)
+int cloudsc2_debug_wave_log(unsigned long long* host_buf, long long nwaves) {
+  static unsigned long long* dev = nullptr;
+  static long long cap = 0;
+  if (!host_buf) {
+    if (dev) (void)hipFree(dev);
+    HIP_TRY(hipMalloc((void**)&dev, (size_t)nwaves * 32));
+    HIP_TRY(hipMemset(dev, 0, (size_t)nwaves * 32));
+    cap = nwaves;
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_wave_log), &dev, sizeof(dev)));
+    return 0;
+  }
+  if (!dev || nwaves > cap) return fail(CLOUDSC2_EINVAL, "wave log not armed");
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(host_buf, dev, (size_t)nwaves * 32, hipMemcpyDeviceToHost));
+  return 0;
+}
+#endif
 
 void cloudsc2_set_math_mode(int precise) { g_precise.store(precise ? 1 : 0); }
 int cloudsc2_get_math_mode(void) { return g_precise.load(); }
@@ -632,6 +688,7 @@ int cloudsc2_nl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
   if (precise_of(prm)) f |= C2F_PRECISE;
   if (args.c.evap) f |= C2F_EVAP;
   if (!prm->lphylin && !prm->ldrain1d) f |= C2F_NOLIN;  // cloudsc2.F90:349 (CLOUDSC2TL / CLOUDSC2AD have the LPHYLIN form only)
+  args.g.fair = nl_fair(g.ncols_pad, args.c.evap != 0);
   if (fits_off32(g, nproma, nlev, {s.full, s.half, s.cml, s.clv, s.loc, (long long)zero_plane.block_stride})) f |= C2F_OFF32;
   return launch_variant(g_nl_kernels[f], args, g.ncols_pad, (hipStream_t)stream);
 }
@@ -666,6 +723,10 @@ int cloudsc2_tl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
   if (precise_of(prm)) f |= C2F_PRECISE;
   if (args.c.evap) f |= C2F_EVAP;
   if (fits_off32(g, nproma, nlev, {s.full, s.half, s.cml, s.clv, s.loc, sp.full, sp.half, sp.cml, sp.clv, sp.loc})) f |= C2F_OFF32;
+  // the fp32 TL variants that run three waves per SIMD (tl_kernel's launch bounds) share their SIMDs like the NL kernel does:
+  // -3.7 % at 160 000 columns with the waves kept abreast; the fp64 TL and both adjoints run one wave per SIMD and lose 1-5 %
+  // (profiles/r03_wave_times.txt)
+  if (sizeof(real_t) == 4 && (f & C2F_OFF32) && !(f & C2F_EVAP)) args.g.fair = nl_fair(g.ncols_pad, false);
   return launch_variant(g_tl_kernels[f], args, g.ncols_pad, (hipStream_t)stream);
 }
 
@@ -848,7 +909,7 @@ int cloudsc2_adjoint_norms_launch(int nproma, int nlev, int ngptot, const clouds
   if (!device_ok()) return fail(CLOUDSC2_ENODEVICE, "no HIP device available (this library has no CPU path)");
   Geom g;
   long long nblocks = ((long long)ngptot + nproma - 1) / nproma;
-  g.nproma = nproma; g.nlev = nlev; g.ngptot = ngptot; g.ncols_pad = nblocks * nproma; g.kb0 = g.kb1 = 0;
+  g.nproma = nproma; g.nlev = nlev; g.ngptot = ngptot; g.ncols_pad = nblocks * nproma; g.kb0 = g.kb1 = 0; g.fair = 0;
   dim3 grid(grid_for(g.ncols_pad, kBlock)), block(kBlock);
   int rc;
   if (y) {

@@ -73,7 +73,7 @@ static void hc_out(const cloudsc2_outputs& out, Strides& s, OutPtrs& p) {
 static Geom hc_geom(int nproma, int nlev, int ngptot) {
   Geom g;
   long long nb = ((long long)ngptot + nproma - 1) / nproma;
-  g.nproma = nproma; g.nlev = nlev; g.ngptot = ngptot; g.ncols_pad = nb * nproma; g.kb0 = g.kb1 = 0;
+  g.nproma = nproma; g.nlev = nlev; g.ngptot = ngptot; g.ncols_pad = nb * nproma; g.kb0 = g.kb1 = 0; g.fair = 0;
   return g;
 }
 

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""When do the waves of one NL launch start and finish, and where do they run?  Needs a diagnostic build of the library:
+    hipcc <CXXFLAGS of csrc/Makefile> -DC2_WAVE_TIMES -shared -o /tmp/wt.so csrc/cloudsc2_kernels.hip
+    CLOUDSC2_LIB=/tmp/wt.so python tools/wave_times.py [NGPTOT [NPROMA]]
+Prints the distribution of the waves' start and end times (microseconds after the first wave's start; 100 MHz clock, 10 ns
+resolution) for a launch in steady state, per XCD and per number of waves sharing a SIMD."""
+import ctypes as C
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import dwarf_p_cloudsc2_tl_ad_amd as c2  # noqa: E402
+from dwarf_p_cloudsc2_tl_ad_amd import binding as B  # noqa: E402
+
+ngptot = int(sys.argv[1]) if len(sys.argv) > 1 else 160000
+nproma = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+tab = c2.synthetic_table()
+prm = c2.default_params(c2.ceta_from_table(tab))
+ds = c2.DeviceState.from_table(tab, nproma, ngptot)
+nwaves = (ds.nb * nproma + 127) // 128 * 2
+for _ in range(30):
+    ds.nl(prm)
+torch.cuda.synchronize()
+log = B.lib.cloudsc2_debug_wave_log
+log.argtypes = [C.c_void_p, C.c_longlong]
+log.restype = C.c_int
+out = []
+for rep in range(5):
+    B.check(log(None, nwaves))
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record(); ds.nl(prm); ev1.record()
+    torch.cuda.synchronize()
+    buf = np.zeros((nwaves, 4), dtype=np.uint64)
+    B.check(log(buf.ctypes.data, nwaves))
+    ok = buf[:, 1] > 0
+    t0 = buf[ok, 0].astype(np.int64); t1 = buf[ok, 1].astype(np.int64)
+    base = t0.min()
+    start = (t0 - base) / 100.0; end = (t1 - base) / 100.0; dur = end - start
+    hw = buf[ok, 2].astype(np.int64); xcc = buf[ok, 3].astype(np.int64) & 0xf
+    simd = (hw >> 4) & 3; cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
+    slot = xcc * 100000 + se * 10000 + sh * 1000 + cu * 10 + simd  # one SIMD
+    uniq, inv, cnt = np.unique(slot, return_inverse=True, return_counts=True)
+    share = cnt[inv]  # waves of this launch on the same SIMD
+    q = lambda a: [round(float(np.percentile(a, p)), 1) for p in (0, 10, 50, 90, 99, 100)]  # noqa: E731
+    r = {"event_ms": ev0.elapsed_time(ev1), "waves": int(ok.sum()), "simds_used": int(len(uniq)),
+         "start_us_p0_10_50_90_99_100": q(start), "end_us": q(end), "duration_us": q(dur),
+         "waves_per_simd_hist": {int(k): int(v) for k, v in zip(*np.unique(cnt, return_counts=True))},
+         "end_us_median_by_share": {int(k): round(float(np.median(end[share == k])), 1) for k in np.unique(share)},
+         "duration_us_median_by_share": {int(k): round(float(np.median(dur[share == k])), 1) for k in np.unique(share)},
+         "end_us_median_by_xcd": {int(k): round(float(np.median(end[xcc == k])), 1) for k in np.unique(xcc)},
+         "waves_by_xcd": {int(k): int((xcc == k).sum()) for k in np.unique(xcc)}}
+    out.append(r)
+    if os.environ.get("WAVE_TIMES_RAW"):
+        np.save(os.environ["WAVE_TIMES_RAW"] + f"_{ngptot}_{rep}.npy", buf)
+print(json.dumps({"ngptot": ngptot, "nproma": nproma, "launches": out}, indent=1))
