@@ -359,7 +359,8 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
   static_assert(LIN || !CKPT, "CLOUDSC2AD's trajectory has the LPHYLIN form only");
   LaneOff o; bool active;
   if (!lane_setup(&a->g, &a->s, gcol, o, active)) return;
-  const int nlev = a->g.nlev, nproma = a->g.nproma, fair = a->g.fair;
+  const int nlev = a->g.nlev, nproma = a->g.nproma;
+  const int fair = CKPT ? 0 : a->g.fair;  // (the adjoint's trajectory pass runs one wave per SIMD: compiled without the priority code)
   const real_t lam = PERT ? a->lam : RC(0.0);
   real_t* zero_plane = a->zero_plane;
   long long ozero = 0;
@@ -410,7 +411,7 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
   // one level: `cur` holds the raw inputs of level jk (requested one level ago), `nxt` receives those of level jk+1
   auto step = [&](int jk, RawLevel& cur, RawLevel& nxt) {
     const bool last = (jk == nlev - 1);
-    progress_priority(jk, fair);
+    if (!CKPT) progress_priority(jk, fair);
     NlArgsP ap = a;  // field pointers are re-read from the kernel-argument segment every level (transient SGPRs);
     C2_LAUNDER(ap);  // the physical constants stay resident
     // request everything level jk+1 needs now; nothing below touches `nxt` before the end of this level, so the
@@ -475,7 +476,11 @@ C2_HD void tl_column(long long gcol, TlArgsP a) {
   if (!lane_setup(&a->g, &a->s, gcol, o, active)) return;
   lane_setup(&a->g, &a->sp, gcol, op, active);
   if (!active) return;
-  const int nlev = a->g.nlev, nproma = a->g.nproma, fair = a->g.fair;
+  const int nlev = a->g.nlev, nproma = a->g.nproma;
+  // only the fp32 variants that run three waves per SIMD (tl_kernel's launch bounds) share their SIMDs; the others -- all fp64
+  // ones -- are compiled without the priority code (one more live SGPR costs the register-tight fp64 kernel 4 %)
+  constexpr bool FAIRV = sizeof(real_t) == 4 && (F & C2F_OFF32) != 0 && !EVAP;
+  const int fair = FAIRV ? a->g.fair : 0;
   LevelTabP tab = (LevelTabP)a->tab;
   ConstsP c = C2_CONSTS(a);
   InPtrsP in = &a->in, din = &a->din;
@@ -508,7 +513,7 @@ C2_HD void tl_column(long long gcol, TlArgsP a) {
   // look-ahead 3 % slower at 160 000 columns and equal at 1 M: the full level of distance is what hides HBM latency here.
   for (int jk = 0; jk < nlev; ++jk) {
     const bool last = (jk == nlev - 1);
-    progress_priority(jk, fair);  // (set for the fp32 variants that run three waves per SIMD only, see cloudsc2_tl_launch)
+    if (FAIRV) progress_priority(jk, fair);
     TlArgsP ap = a;
     C2_LAUNDER(ap);
     in = &ap->in; din = &ap->din;
