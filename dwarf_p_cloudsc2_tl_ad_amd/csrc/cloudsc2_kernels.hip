@@ -199,7 +199,9 @@ template <unsigned F>
 __global__ void __launch_bounds__(kBlock, (C2_TL_WAVES > 0) ? C2_TL_WAVES
                                           : (sizeof(real_t) == 4 && (F & C2F_OFF32) && !(F & C2F_EVAP)) ? 3 : 1)
 tl_kernel(TlArgs args) {
+  C2_KERNEL_BODY(C2_WAVE_LOG_BEGIN);
   C2_KERNEL_BODY((tl_column<F>(global_column(), kernarg<TlArgs>())));
+  C2_KERNEL_BODY(C2_WAVE_LOG_END);
 }
 
 // C2_AD_FUSED=1: one kernel runs a column's trajectory pass and then its reverse pass (waves in the bandwidth-heavy
@@ -218,12 +220,16 @@ tl_kernel(TlArgs args) {
 constexpr long long kAdSplitBelow = 400000;
 template <unsigned F>
 __global__ void C2_BOUNDS(C2_AD_WAVES) ad_reverse_kernel(AdArgs args) {
+  C2_KERNEL_BODY(C2_WAVE_LOG_BEGIN);
   C2_KERNEL_BODY((ad_reverse_column<F>(global_column(), kernarg<AdArgs>())));
+  C2_KERNEL_BODY(C2_WAVE_LOG_END);
 }
 template <unsigned F>
 __global__ void C2_BOUNDS(C2_AD_WAVES) ad_kernel(AdArgs args) {
+  C2_KERNEL_BODY(C2_WAVE_LOG_BEGIN);
   C2_KERNEL_BODY((nl_column<(F & ~C2F_ASSIGN) | C2F_CKPT>(global_column(), &kernarg<AdArgs>()->nl)));
   C2_KERNEL_BODY((ad_reverse_column<F>(global_column(), kernarg<AdArgs>())));
+  C2_KERNEL_BODY(C2_WAVE_LOG_END);
 }
 
 // Variant tables: kernel<F> for every valid flag combination F, indexed by F (see C2F_* in cloudsc2_column.hpp).

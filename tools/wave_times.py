@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """When do the waves of one NL launch start and finish, and where do they run?  Needs a diagnostic build of the library:
     hipcc <CXXFLAGS of csrc/Makefile> -DC2_WAVE_TIMES -shared -o /tmp/wt.so csrc/cloudsc2_kernels.hip
-    CLOUDSC2_LIB=/tmp/wt.so python tools/wave_times.py [NGPTOT [NPROMA]]
+    CLOUDSC2_LIB=/tmp/wt.so python tools/wave_times.py [NGPTOT [NPROMA [nl|tl|ad|ad_reverse]]]
 Prints the distribution of the waves' start and end times (microseconds after the first wave's start; 100 MHz clock, 10 ns
 resolution) for a launch in steady state, per XCD and per number of waves sharing a SIMD."""
 import ctypes as C
@@ -20,10 +20,20 @@ ngptot = int(sys.argv[1]) if len(sys.argv) > 1 else 160000
 nproma = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 tab = c2.synthetic_table()
 prm = c2.default_params(c2.ceta_from_table(tab))
+kind = sys.argv[3] if len(sys.argv) > 3 else "nl"
 ds = c2.DeviceState.from_table(tab, nproma, ngptot)
 nwaves = (ds.nb * nproma + 127) // 128 * 2
+if kind == "nl":
+    step = lambda: ds.nl(prm)  # noqa: E731
+else:
+    ds.satur(prm)
+    inc, dout = c2.FlatFields.pair(ds.nb, ds.nlev, ds.nproma, ds.device)
+    ds.increments(zero_supsat=(kind != "tl"), into=inc)
+    ds.tl(prm, inc, dout)
+    step = {"tl": lambda: ds.tl(prm, inc, dout), "ad": lambda: ds.ad(prm, inc, dout, None),
+            "ad_reverse": lambda: ds.ad(prm, inc, dout, None, sweep="reverse")}[kind]
 for _ in range(30):
-    ds.nl(prm)
+    step()
 torch.cuda.synchronize()
 log = B.lib.cloudsc2_debug_wave_log
 log.argtypes = [C.c_void_p, C.c_longlong]
@@ -32,7 +42,7 @@ out = []
 for rep in range(5):
     B.check(log(None, nwaves))
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record(); ds.nl(prm); ev1.record()
+    ev0.record(); step(); ev1.record()
     torch.cuda.synchronize()
     buf = np.zeros((nwaves, 4), dtype=np.uint64)
     B.check(log(buf.ctypes.data, nwaves))
@@ -46,7 +56,20 @@ for rep in range(5):
     uniq, inv, cnt = np.unique(slot, return_inverse=True, return_counts=True)
     share = cnt[inv]  # waves of this launch on the same SIMD
     q = lambda a: [round(float(np.percentile(a, p)), 1) for p in (0, 10, 50, 90, 99, 100)]  # noqa: E731
-    r = {"event_ms": ev0.elapsed_time(ev1), "waves": int(ok.sum()), "simds_used": int(len(uniq)),
+    order = np.argsort(start)
+    # rounds: for every SIMD, its waves in start order -> (start, end) of the 1st, 2nd, 3rd ... wave it ran
+    rounds = {}
+    for sl in uniq[:]:
+        pass
+    per_simd = {}
+    for i in order:
+        per_simd.setdefault(int(slot[i]), []).append((float(start[i]), float(end[i])))
+    nth = {}
+    for v in per_simd.values():
+        for k, (a_, b_) in enumerate(v):
+            nth.setdefault(k, []).append((a_, b_, b_ - a_))
+    r = {"event_ms": ev0.elapsed_time(ev1), "kernel": kind,
+         "nth_wave_of_its_simd_start_end_duration_us_median": {k: [round(float(np.median([x[j] for x in v])), 1) for j in range(3)] + [len(v)] for k, v in sorted(nth.items()) if k < 8}, "waves": int(ok.sum()), "simds_used": int(len(uniq)),
          "start_us_p0_10_50_90_99_100": q(start), "end_us": q(end), "duration_us": q(dur),
          "waves_per_simd_hist": {int(k): int(v) for k, v in zip(*np.unique(cnt, return_counts=True))},
          "end_us_median_by_share": {int(k): round(float(np.median(end[share == k])), 1) for k in np.unique(share)},
