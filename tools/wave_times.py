@@ -58,9 +58,6 @@ for rep in range(5):
     q = lambda a: [round(float(np.percentile(a, p)), 1) for p in (0, 10, 50, 90, 99, 100)]  # noqa: E731
     order = np.argsort(start)
     # rounds: for every SIMD, its waves in start order -> (start, end) of the 1st, 2nd, 3rd ... wave it ran
-    rounds = {}
-    for sl in uniq[:]:
-        pass
     per_simd = {}
     for i in order:
         per_simd.setdefault(int(slot[i]), []).append((float(start[i]), float(end[i])))
