@@ -536,9 +536,9 @@ int check_geom(const cloudsc2_params* prm, int nproma, int nlev, int ngptot, Geo
 // (exactly 3 per SIMD) +-1 %; with more than one round the age order is better (262 144 columns +4 %, 1 M +2 %): off there.
 // CLOUDSC2_FAIR=0|1 forces it (measurements only).
 int nl_fair(long long ncols_pad, bool evap) {
+  (void)evap;  // (the evaporation variants run two or three waves per SIMD as well)
   static const char* e = getenv("CLOUDSC2_FAIR");
   if (e && *e) return atoi(e) != 0;
-  if (evap) return 0;  // one wave per SIMD: nobody to yield to
   static int simds = 0;
   if (!simds) {
     int dev = 0, cus = 0;
