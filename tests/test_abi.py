@@ -121,3 +121,33 @@ def test_device_state_layout_lists_every_array_once_in_the_librarys_order():
     body = body[:body.index("\n}\n")]
     lib_order = [m.upper() for m in re.findall(r"d\.(\w+) = a(?:in|out)\.take", body)]
     assert lib_order == [n.upper() for n in DeviceState.ORDER], (lib_order, DeviceState.ORDER)
+
+
+def test_a_plain_c_caller_compiles_and_links_against_the_abi(tmp_path):
+    """The boundary is a C ABI: every header under include/ must be valid C99 on its own (no C++-isms, no torch types), and a C
+    program must link against the shared library and get the reference drivers' verdicts and the no-device error from it."""
+    import glob
+    import subprocess
+
+    csrc = os.path.join(ROOT, "dwarf_p_cloudsc2_tl_ad_amd", "csrc")
+    libname = "cloudsc2_hip_sp" if B.SINGLE else "cloudsc2_hip"
+    src = tmp_path / "caller.c"
+    src.write_text("".join(f'#include "{os.path.basename(h)}"\n' for h in sorted(glob.glob(os.path.join(ROOT, "include", "*.h")))) + r"""
+#include <stdio.h>
+int main(void) {
+    cloudsc2_params p;
+    double z[10];
+    int itest = -1, k, ok;
+    cloudsc2_params_default(&p);
+    for (k = 0; k < 10; ++k) z[k] = 1.0 + 1e-7;           /* ratios this close to one at every lambda: PASSED, penalty 0 */
+    ok = cloudsc2_taylor_verdict(z, &itest);
+    printf("%d %d %d %d\n", ok, itest, cloudsc2_adjoint_verdict(100.0), cloudsc2_adjoint_verdict(1.0e6));
+    return 0;
+}
+""")
+    exe = tmp_path / "caller"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror"] + (["-DCLOUDSC2_SINGLE"] if B.SINGLE else []) +
+                   ["-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), "-L", csrc, f"-l{libname}", f"-Wl,-rpath,{csrc}"],
+                   check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert out[0] == "1" and out[2] == "1" and out[3] == "0", out   # PASSED; 100 x eps is TEST OK, 1e6 x eps is not
