@@ -160,26 +160,32 @@ C2_HD void stg(real_t* p, unsigned byte_off, real_t v) {
 #endif
 }
 
-template <bool HAS_QSAT, class OT>
+// STREAM = false: plain loads for data that other waves read too (the Taylor sweep, whose waves share cache lines)
+template <bool STREAM>
+C2_HD real_t ldx(const real_t* p, long long i) { return STREAM ? ldg(p, i) : p[i]; }
+template <bool STREAM>
+C2_HD real_t ldx(const real_t* p, unsigned byte_off) { return STREAM ? ldg(p, byte_off) : *(const real_t*)((const char*)p + byte_off); }
+
+template <bool HAS_QSAT, class OT, bool STREAM = true>
 C2_HD void load_level(InPtrsP pp, const LaneOffT<OT>& o, int nproma, int nlev, int jk, RawLevel& r) {
   const InPtrs p = *pp;
   const OT d = level_off(OT(), jk, nproma), d1 = d + row_off(OT(), nproma);
-  r.paph_k1 = ldg(p.paph, o.half + d1);
-  r.lu_k1 = (jk + 1 < nlev) ? ldg(p.lu, o.full + d1) : RC(0.0);
-  r.pap = ldg(p.pap, o.full + d);
-  r.q = ldg(p.q, o.full + d);
-  r.t = ldg(p.t, o.full + d);
-  r.l = ldg(p.l, o.clv + d);
-  r.i = ldg(p.i, o.clv + d);
-  r.lude = ldg(p.lude, o.full + d);
-  r.mfu = ldg(p.mfu, o.full + d);
-  r.mfd = ldg(p.mfd, o.full + d);
-  r.gt = ldg(p.gt, o.cml + d);
-  r.gq = ldg(p.gq, o.cml + d);
-  r.gl = ldg(p.gl, o.cml + d);
-  r.gi = ldg(p.gi, o.cml + d);
-  r.supsat = ldg(p.supsat, o.full + d);
-  if (HAS_QSAT) r.qsat = ldg(p.qsat, o.full + d);
+  r.paph_k1 = ldx<STREAM>(p.paph, o.half + d1);
+  r.lu_k1 = (jk + 1 < nlev) ? ldx<STREAM>(p.lu, o.full + d1) : RC(0.0);
+  r.pap = ldx<STREAM>(p.pap, o.full + d);
+  r.q = ldx<STREAM>(p.q, o.full + d);
+  r.t = ldx<STREAM>(p.t, o.full + d);
+  r.l = ldx<STREAM>(p.l, o.clv + d);
+  r.i = ldx<STREAM>(p.i, o.clv + d);
+  r.lude = ldx<STREAM>(p.lude, o.full + d);
+  r.mfu = ldx<STREAM>(p.mfu, o.full + d);
+  r.mfd = ldx<STREAM>(p.mfd, o.full + d);
+  r.gt = ldx<STREAM>(p.gt, o.cml + d);
+  r.gq = ldx<STREAM>(p.gq, o.cml + d);
+  r.gl = ldx<STREAM>(p.gl, o.cml + d);
+  r.gi = ldx<STREAM>(p.gi, o.cml + d);
+  r.supsat = ldx<STREAM>(p.supsat, o.full + d);
+  if (HAS_QSAT) r.qsat = ldx<STREAM>(p.qsat, o.full + d);
 }
 
 // Perturbed state of the Taylor test: x5 = x + lambda*(0.01*x) (cloudsc_driver_tl_mod.F90:156-171,200-215).
@@ -463,6 +469,127 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
     step(jk, ra, rb);
     ra = rb;
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Taylor test: the ten perturbed NL runs of CLOUDSC_DRIVER_TL and the level sums of its ERROR_NORM calls
+// (cloudsc_driver_tl_mod.F90:21-31,197-244) in ONE sweep -- the lambdas lie on the lanes of the wave
+// ---------------------------------------------------------------------------------------------------------
+// A wave holds kTaylorCols columns x kTaylorLambdas lambdas: lane (c, k) runs the NL sweep of column c on the state perturbed by
+// lambda_k = 10^-(k+1), exactly what nl_column<F | C2F_PERT> does, but stores nothing: it reads the BASE run's outputs of the
+// level instead and keeps sum_levels(F - F5) of the ten compared fields in registers; the lane also sums TL output field k of its
+// column (the denominators).  The ten lanes of a column request the same addresses (one 8-byte word per plane and level), so the
+// state is read from HBM once for all ten runs instead of once per run, no perturbed outputs are written and re-read, and the
+// code is the NL sweep's (one level_forward per lane and level; 60 of 64 lanes work).
+//   colsum[(k*10 + f)*ncols_pad + g] = sum_levels(F_f - F5_f(lambda_k)) of column g     (k, f = 0..9; order of ERROR_NORM calls)
+//   colsum[(100 + f)*ncols_pad + g]  = sum_levels(TL_f) of column g
+constexpr int kTaylorLambdas = 10, kTaylorCols = 64 / kTaylorLambdas;
+struct TenPtrs { const real_t* p[10]; long long stride[10]; int nlevx[10]; };  // the ten compared fields, cloudsc_driver_tl_mod.F90:233-242
+struct TaylorArgs {
+  NlArgs nl;      // nl.in: the unperturbed state; nl.out: the outputs of the BASE run (read here); nl.lam, zero_plane, ckpt unused
+  TenPtrs tl;     // the TL outputs
+  real_t lam[kTaylorLambdas];
+  double* colsum;
+};
+typedef const C2_CONST_AS TaylorArgs* TaylorArgsP;
+
+template <class OT>
+C2_HD void load_out(OutPtrsP pp, const LaneOffT<OT>& o, int nproma, int jk, LevelOut& v) {
+  const OutPtrs p = *pp;
+  const OT d = level_off(OT(), jk, nproma);
+  v.tent = ldx<false>(p.tent, o.loc + d);
+  v.tenq = ldx<false>(p.tenq, o.loc + d);
+  v.tenl = ldx<false>(p.tenl, o.loc + d);
+  v.teni = ldx<false>(p.teni, o.loc + d);
+  v.clc = ldx<false>(p.clc, o.full + d);
+  v.covptot = ldx<false>(p.covptot, o.full + d);
+  const OT d1 = d + row_off(OT(), nproma);
+  v.fplsl = ldx<false>(p.fplsl, o.half + d1);
+  v.fplsn = ldx<false>(p.fplsn, o.half + d1);
+  v.fhpsl = ldx<false>(p.fhpsl, o.half + d1);
+  v.fhpsn = ldx<false>(p.fhpsn, o.half + d1);
+}
+
+// column and lambda index of a thread: wave w holds columns [w*kTaylorCols, (w+1)*kTaylorCols), lane = k*kTaylorCols + c
+C2_HD bool taylor_lane(long long gthread, long long& gcol, int& k) {
+  const int lane = (int)(gthread & 63);
+  k = lane / kTaylorCols;
+  gcol = (gthread >> 6) * kTaylorCols + (lane - k * kTaylorCols);
+  return k < kTaylorLambdas;
+}
+
+template <unsigned F>
+C2_HD void taylor_column(long long gthread, TaylorArgsP ta) {
+  constexpr bool HAS_QSAT = (F & C2F_QSAT) != 0, P = (F & C2F_PRECISE) != 0, EVAP = (F & C2F_EVAP) != 0, OFF32 = (F & C2F_OFF32) != 0;
+  static_assert(!(F & (C2F_PERT | C2F_CKPT | C2F_NOLIN)), "flags of the Taylor sweep: QSAT, PRECISE, EVAP, OFF32");
+  typedef typename std::conditional<OFF32, unsigned, long long>::type OT;
+  long long gcol; int k;
+  if (!taylor_lane(gthread, gcol, k)) return;
+  NlArgsP a = &ta->nl;
+  LaneOff o; bool active;
+  if (!lane_setup(&a->g, &a->s, gcol, o, active) || !active) return;
+  const int nlev = a->g.nlev, nproma = a->g.nproma;
+  const real_t lam = ta->lam[k];
+  LevelTabP tab = (LevelTabP)a->tab;
+  ConstsP c = C2_CONSTS(a);
+  InPtrsP in = &a->in;
+
+  real_t ztrpaus = tropopause<true>(c, tab, in, o, &a->g, lam);
+  RhCrit rh;
+  rhcrit_setup(ztrpaus, rh);
+  real_t paph_surf = RC(0.0);
+  if (EVAP) paph_surf = pert(in->paph[o.half + (long long)nlev * nproma], lam);
+  Carry cy; cy.rfl = RC(0.0); cy.sfl = RC(0.0); cy.covptot = RC(0.0);
+  real_t paph_k = pert(in->paph[o.half], lam);
+  const LaneOffT<OT> ol = lane_off_as<OT>(o);
+
+  // TL output field k of this column (the fluxes live on half levels: level jk's flux is the one at jk+1, like LevelOut's;
+  // their top value is zero in every run)
+  const long long ibl = gcol / nproma;
+  const real_t* tlk = ta->tl.p[k] + ibl * ta->tl.stride[k] + (gcol - ibl * nproma) + (ta->tl.nlevx[k] > nlev ? nproma : 0);
+  double s[10] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, stl = 0.0;
+
+  auto step = [&](int jk, RawLevel& cur, RawLevel& nxt) {
+    const bool last = (jk == nlev - 1);
+    NlArgsP ap = a;
+    C2_LAUNDER(ap);
+    if (!last) load_level<HAS_QSAT, OT, false>(&ap->in, ol, nproma, nlev, jk + 1, nxt);
+    LevelOut base;
+    load_out(&ap->out, ol, nproma, jk, base);
+    const real_t tlv = tlk[(long long)jk * nproma];
+
+    if (!HAS_QSAT) cur.qsat = satur_point<P>(c, cur.pap, cur.t);  // SATUR on the unperturbed PAP, PT
+    perturb_raw(cur, lam);
+    LevelCst kc;
+    level_cst(tab, jk, last, kc);
+    LevelIn x;
+    make_level_in(cur, paph_k, paph_surf, x);
+    LevelTraj tr;
+    LevelOut lo;
+    level_forward<P, EVAP, true>(c, kc, rh, x, cy, tr, lo);
+    s[0] += (double)(base.tent - lo.tent); s[1] += (double)(base.tenq - lo.tenq);
+    s[2] += (double)(base.tenl - lo.tenl); s[3] += (double)(base.teni - lo.teni);
+    s[4] += (double)(base.clc - lo.clc);
+    s[5] += (double)(base.fplsl - lo.fplsl); s[6] += (double)(base.fplsn - lo.fplsn);
+    s[7] += (double)(base.fhpsl - lo.fhpsl); s[8] += (double)(base.fhpsn - lo.fhpsn);
+    s[9] += (double)(base.covptot - lo.covptot);
+    stl += (double)tlv;
+    paph_k = cur.paph_k1;
+  };
+
+  RawLevel ra, rb;
+  load_level<HAS_QSAT, OT, false>(in, ol, nproma, nlev, 0, ra);
+  rb = ra;
+#pragma clang loop unroll(disable)
+  for (int jk = 0; jk < nlev; ++jk) {
+    step(jk, ra, rb);
+    ra = rb;
+  }
+  double* cs = ta->colsum;
+  const long long np = a->g.ncols_pad;
+#pragma unroll
+  for (int f = 0; f < 10; ++f) cs[(long long)(k * 10 + f) * np + gcol] = s[f];
+  cs[(long long)(100 + k) * np + gcol] = stl;
 }
 
 // ---------------------------------------------------------------------------------------------------------

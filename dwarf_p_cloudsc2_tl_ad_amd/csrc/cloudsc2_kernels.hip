@@ -232,6 +232,13 @@ __global__ void C2_BOUNDS(C2_AD_WAVES) ad_kernel(AdArgs args) {
   C2_KERNEL_BODY(C2_WAVE_LOG_END);
 }
 
+// The ten perturbed NL runs of the Taylor test in one sweep, the lambdas on the lanes (taylor_column): the grid is over THREADS,
+// 64 per kTaylorCols columns.
+template <unsigned F>
+__global__ void __launch_bounds__(kBlock) taylor_kernel(TaylorArgs args) {
+  C2_KERNEL_BODY((taylor_column<F>(global_column(), kernarg<TaylorArgs>())));
+}
+
 // Variant tables: kernel<F> for every valid flag combination F, indexed by F (see C2F_* in cloudsc2_column.hpp).
 template <class Args> using KernelFn = void (*)(Args);
 #define C2_VARIANT_TABLE(table, kern, Args, NF, valid_expr)                                                        \
@@ -246,6 +253,7 @@ C2_VARIANT_TABLE(g_nl_kernels, nl_kernel, NlArgs, 128, (F & C2F_CKPT) ? ((F & C2
 C2_VARIANT_TABLE(g_tl_kernels, tl_kernel, TlArgs, 64, !(F & 16u))
 C2_VARIANT_TABLE(g_ad_reverse_kernels, ad_reverse_kernel, AdArgs, 64, !(F & 16u))
 C2_VARIANT_TABLE(g_ad_kernels, ad_kernel, AdArgs, 64, C2_AD_FUSED != 0 && !(F & 16u))
+C2_VARIANT_TABLE(g_taylor_kernels, taylor_kernel, TaylorArgs, 64, !(F & (C2F_PERT | C2F_CKPT)))
 
 // ---------------------------------------------------------------------------------------------------------
 // Data-format kernels either side of the path: the input file holds KLON (=100) columns,
@@ -379,14 +387,13 @@ __device__ __forceinline__ double wave_max(double v) {
 // ERROR_NORM sums (cloudsc_driver_tl_mod.F90:21-31): one thread block per NPROMA block, lanes stride the
 // block's active columns, per-lane level sums, wave shuffles, then one LDS stage.
 // sums[(ibl*10 + f)*2 + {0,1}] = { sum(F - F5), sum(TL*lambda) }.
-struct TenPtrs { const real_t* p[10]; long long stride[10]; int nlevx[10]; };
+// (TenPtrs: cloudsc2_column.hpp)
 
-// `nproma` is the block of the STATISTIC (the caller's NPROMA: ERROR_NORM sums over one NPROMA block); the arrays are blocked by
-// `nproma_phys` (the same, except for resident states the library blocks differently from the caller).  The 256 threads of a
-// workgroup are laid over the block as (column, level slice): all of them work whatever NPROMA is -- with one thread per column
-// only, the README's NPROMA 32 left 7 of 8 lanes idle and the ten sums launches cost more than the twelve sweeps they follow.
-__global__ void __launch_bounds__(256) taylor_sums_kernel(int nproma, int nproma_phys, int nlev, int ngptot, TenPtrs f, TenPtrs f5,
-                                                          TenPtrs tl, double lambda, double* sums) {
+// The 256 threads of a workgroup are laid over the block as (column, level slice): all of them work whatever NPROMA is -- with one
+// thread per column only, the README's NPROMA 32 left 7 of 8 lanes idle.  (For ONE lambda and perturbed outputs that are in memory;
+// the Taylor driver itself runs all ten lambdas in one sweep that stores nothing, taylor_kernel + taylor_reduce_kernel.)
+__global__ void __launch_bounds__(256) taylor_sums_kernel(int nproma, int nlev, int ngptot, TenPtrs f, TenPtrs f5, TenPtrs tl,
+                                                          double lambda, double* sums) {
   (void)nlev;
   const int ibl = blockIdx.x;
   const int icend = min(nproma, ngptot - ibl * nproma);
@@ -399,12 +406,11 @@ __global__ void __launch_bounds__(256) taylor_sums_kernel(int nproma, int nproma
     const int nl = f.nlevx[fi];
     if (slice < nslice) {
       for (int jl = jl0; jl < icend; jl += ncolt) {
-        const long long g = (long long)ibl * nproma + jl, pb = g / nproma_phys, pj = g - pb * nproma_phys;
-        const real_t* a = f.p[fi] + pb * f.stride[fi] + pj;
-        const real_t* b = f5.p[fi] + pb * f5.stride[fi] + pj;
-        const real_t* t = tl.p[fi] + pb * tl.stride[fi] + pj;
+        const real_t* a = f.p[fi] + (long long)ibl * f.stride[fi] + jl;
+        const real_t* b = f5.p[fi] + (long long)ibl * f5.stride[fi] + jl;
+        const real_t* t = tl.p[fi] + (long long)ibl * tl.stride[fi] + jl;
         for (int jk = slice; jk < nl; jk += nslice) {
-          long long d = (long long)jk * nproma_phys;
+          long long d = (long long)jk * nproma;
           s0 += a[d] - b[d];
           s1 += t[d] * lambda;
         }
@@ -423,6 +429,27 @@ __global__ void __launch_bounds__(256) taylor_sums_kernel(int nproma, int nproma
     }
     __syncthreads();
   }
+}
+
+// Second stage of the Taylor sweep: the per-column level sums of taylor_kernel summed over the active columns of each block of
+// the STATISTIC (ERROR_NORM sums over one block of the caller's NPROMA), in column order (deterministic), into the layout of
+// taylor_sums_kernel: sums[((il*nblocks + ibl)*10 + f)*2 + {0,1}] = { sum(F - F5(lambda_il)), sum(TL)*lambda_il }.
+struct TenLambdas { double v[kTaylorLambdas]; };
+__global__ void __launch_bounds__(128) taylor_reduce_kernel(int nproma, int ngptot, long long ncols_pad, long long nblocks, TenLambdas lam,
+                                                            const double* colsum, double* sums) {
+  const long long ibl = blockIdx.x;
+  const int t = threadIdx.x;
+  if (t >= 10 * kTaylorLambdas) return;
+  const int il = t / 10, f = t - 10 * il;
+  const long long c0 = ibl * nproma;
+  const int icend = (int)min((long long)nproma, (long long)ngptot - c0);
+  const double* s1 = colsum + (long long)t * ncols_pad + c0;
+  const double* s2 = colsum + (long long)(10 * kTaylorLambdas + f) * ncols_pad + c0;
+  double r0 = 0.0, r1 = 0.0;
+  for (int j = 0; j < icend; ++j) { r0 += s1[j]; r1 += s2[j]; }
+  double* o = sums + (((long long)il * nblocks + ibl) * 10 + f) * 2;
+  o[0] = r0;
+  o[1] = r1 * lam.v[il];
 }
 
 __device__ __forceinline__ void atomic_max_pos(double* addr, double v) {
@@ -883,16 +910,9 @@ static int ten_ptrs(const cloudsc2_outputs* o, int nlev, TenPtrs& t) {
   return 0;
 }
 
-static int taylor_sums_launch_impl(int nproma, int nproma_phys, int nlev, int ngptot, const cloudsc2_outputs* f,
-                                   const cloudsc2_outputs* f_pert, const cloudsc2_outputs* tl, double lambda, double* sums, void* stream);
 int cloudsc2_taylor_sums_launch(int nproma, int nlev, int ngptot, const cloudsc2_outputs* f,
                                 const cloudsc2_outputs* f_pert, const cloudsc2_outputs* tl, double lambda,
                                 double* sums, void* stream) {
-  return taylor_sums_launch_impl(nproma, nproma, nlev, ngptot, f, f_pert, tl, lambda, sums, stream);
-}
-
-static int taylor_sums_launch_impl(int nproma, int nproma_phys, int nlev, int ngptot, const cloudsc2_outputs* f,
-                                   const cloudsc2_outputs* f_pert, const cloudsc2_outputs* tl, double lambda, double* sums, void* stream) {
   if (!f || !f_pert || !tl || !sums) return fail(CLOUDSC2_EINVAL, "NULL argument");
   if (!device_ok()) return fail(CLOUDSC2_ENODEVICE, "no HIP device available (this library has no CPU path)");
   TenPtrs a, b, c;
@@ -901,8 +921,53 @@ static int taylor_sums_launch_impl(int nproma, int nproma_phys, int nlev, int ng
   if ((rc = ten_ptrs(f_pert, nlev, b))) return rc;
   if ((rc = ten_ptrs(tl, nlev, c))) return rc;
   int nblocks = (ngptot + nproma - 1) / nproma;
-  hipLaunchKernelGGL(taylor_sums_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, nproma, nproma_phys, nlev, ngptot, a, b,
-                     c, lambda, sums);
+  hipLaunchKernelGGL(taylor_sums_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, nproma, nlev, ngptot, a, b, c, lambda, sums);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int cloudsc2_taylor_sweep_work_doubles(int nproma, int ngptot, long long* n) {
+  if (!n || nproma < 1 || ngptot < 1) return fail(CLOUDSC2_EINVAL, "taylor sweep: bad argument");
+  *n = (long long)(10 * kTaylorLambdas + 10) * (((long long)ngptot + nproma - 1) / nproma) * nproma;
+  return 0;
+}
+
+int cloudsc2_taylor_sweep_launch(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot, int nproma_stat,
+                                 const cloudsc2_inputs* in, const cloudsc2_outputs* out, const cloudsc2_outputs* tl,
+                                 double* work, double* sums, void* stream) {
+  Geom g;
+  int rc = check_geom(prm, nproma, nlev, ngptot, g);
+  if (rc) return rc;
+  if (!in || !out || !tl || !work || !sums) return fail(CLOUDSC2_EINVAL, "NULL argument");
+  if (nproma_stat < 1) return fail(CLOUDSC2_EINVAL, "taylor sweep: the block of the statistic must be >= 1");
+  if (!prm->lphylin && !prm->ldrain1d) return fail(CLOUDSC2_EINVAL, "taylor sweep: CLOUDSC_DRIVER_TL runs with LPHYLIN (cloudsc2tl.F90 has that form only)");
+  Strides s = {0, 0, 0, 0, 0};
+  TaylorArgs args;
+  if ((rc = resolve_in(*in, false, s, args.nl.in))) return rc;
+  if ((rc = resolve_out(*out, true, s, args.nl.out))) return rc;
+  if ((rc = ten_ptrs(tl, nlev, args.tl))) return rc;
+  const LevelTab* tab;
+  if ((rc = get_tables(*prm, &tab, &g.kb0, &g.kb1))) return rc;
+  g.fair = 0;
+  args.nl.c = make_consts(*prm, ptsphy);
+  args.nl.g = g; args.nl.s = s; args.nl.tab = tab;
+  args.nl.zero_plane = nullptr; args.nl.zero_stride = 0; args.nl.lam = 0; args.nl.ckpt = nullptr;
+  TenLambdas lam;
+  for (int il = 0; il < kTaylorLambdas; ++il) {
+    lam.v[il] = pow(10.0, -(double)(il + 1));  // ZLAMBDA=10._JPRB**(-REAL(ILAM,JPRB)), cloudsc_driver_tl_mod.F90:199
+    args.lam[il] = (real_t)lam.v[il];
+  }
+  args.colsum = work;
+  unsigned f = 0;
+  if (in->qsat.ptr) f |= C2F_QSAT;
+  if (precise_of(prm)) f |= C2F_PRECISE;
+  if (args.nl.c.evap) f |= C2F_EVAP;
+  if (fits_off32(g, nproma, nlev, {s.full, s.half, s.cml, s.clv, s.loc})) f |= C2F_OFF32;
+  const long long nwaves = (g.ncols_pad + kTaylorCols - 1) / kTaylorCols;
+  if ((rc = launch_variant(g_taylor_kernels[f], args, nwaves * 64, (hipStream_t)stream))) return rc;
+  const long long nblocks_stat = ((long long)ngptot + nproma_stat - 1) / nproma_stat;
+  hipLaunchKernelGGL(taylor_reduce_kernel, dim3((unsigned)nblocks_stat), dim3(128), 0, (hipStream_t)stream, nproma_stat, ngptot,
+                     g.ncols_pad, nblocks_stat, lam, (const double*)work, sums);
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -346,6 +346,29 @@ class DeviceState:
         fn = B.lib.cloudsc2_ad_launch_assign if assign else B.lib.cloudsc2_ad_launch
         B.check(fn(*geom, C.byref(ai), C.byref(ao), sc, self._stream(stream)))
 
+    def taylor_sums(self, pert_outputs: B.Outputs, tl_out: FlatFields, lam: float, stream=None):
+        """ERROR_NORM sums of ONE lambda from perturbed outputs in memory (cloudsc2_taylor_sums_launch): (NBLOCKS, 10, 2) doubles."""
+        sums = self.torch.zeros((self.nb, 10, 2), dtype=self.torch.float64, device=self.device)
+        o, t = self.traj_outputs(), tl_out.block()
+        B.check(B.lib.cloudsc2_taylor_sums_launch(self.nproma, self.nlev, self.ngptot, C.byref(o), C.byref(pert_outputs), C.byref(t),
+                                                  float(lam), C.c_void_p(sums.data_ptr()), self._stream(stream)))
+        return sums
+
+    def taylor_sweep(self, prm: B.Params, tl_out: FlatFields, nproma_stat: int | None = None, fused_satur: bool = False, stream=None):
+        """The whole lambda loop of the Taylor test in one sweep, the lambdas on the lanes (cloudsc2_taylor_sweep_launch):
+        (10 lambdas, blocks of the statistic, 10 fields, 2) doubles.  The state's outputs must hold the base run."""
+        nps = int(nproma_stat or self.nproma)
+        nbs = (self.ngptot + nps - 1) // nps
+        n = C.c_longlong(0)
+        B.check(B.lib.cloudsc2_taylor_sweep_work_doubles(self.nproma, self.ngptot, C.byref(n)))
+        work = self.torch.empty((n.value,), dtype=self.torch.float64, device=self.device)
+        sums = self.torch.zeros((10, nbs, 10, 2), dtype=self.torch.float64, device=self.device)
+        i, o, t = self.traj_inputs(not fused_satur), self.traj_outputs(), tl_out.block()
+        B.check(B.lib.cloudsc2_taylor_sweep_launch(C.byref(prm), self.ptsphy, self.nproma, self.nlev, self.ngptot, nps, C.byref(i), C.byref(o),
+                                                   C.byref(t), C.c_void_p(work.data_ptr()), C.c_void_p(sums.data_ptr()), self._stream(stream)))
+        self._keep = work  # until the stream has run the sweep
+        return sums
+
     def increments(self, zero_supsat: bool = False, into: FlatFields | None = None) -> FlatFields:
         """dx = 0.01 * x for the 16 inputs (cloudsc_driver_tl_mod.F90:156-171); ZSUPSAT = 0 in the adjoint test
         (cloudsc_driver_ad_mod.F90:139).  `into`: an existing input set (e.g. one half of FlatFields.pair) to fill."""

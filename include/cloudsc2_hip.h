@@ -207,6 +207,22 @@ int cloudsc2_taylor_sums_launch(int nproma, int nlev, int ngptot, const cloudsc2
                                 const cloudsc2_outputs* f_pert, const cloudsc2_outputs* tl, double lambda,
                                 double* sums, void* stream);
 
+/* The lambda loop of the Taylor test in one sweep (cloudsc_driver_tl_mod.F90:197-244: the ten perturbed CLOUDSC2 calls,
+ * ZLAMBDA = 10^-1 .. 10^-10, each followed by the ten ERROR_NORM calls).  The lambdas lie on the lanes of a wave -- 6 columns x
+ * 10 lambdas per wave64 --, every lane runs the NL sweep of its column on x + lambda*(0.01*x) (:200-215), compares each level's
+ * outputs with the BASE run's (`out`, read) in registers and sums TL output field k of its column; a second small kernel sums
+ * the per-column results over the active columns of each block of the statistic (`nproma_stat`: the caller's NPROMA, which may
+ * differ from the arrays' blocking `nproma`).  The state is read once for all ten runs and no perturbed outputs are written.
+ *   in   the unperturbed state (qsat: the SATUR result, or NULL = SATUR in the sweep)
+ *   out  the outputs of the base run (cloudsc2_nl_launch on the same state), tl the TL outputs (cloudsc2_tl_launch)
+ *   work device scratch of cloudsc2_taylor_sweep_work_doubles(nproma, ngptot) doubles
+ *   sums(2, 10, nblocks_stat, 10) device doubles, the layout of ten cloudsc2_taylor_sums_launch calls one after the other:
+ *        sums[((il*nblocks_stat + ibl)*10 + f)*2 + {0,1}] = { sum(F - F5(lambda_il)), sum(TL)*lambda_il }. */
+int cloudsc2_taylor_sweep_work_doubles(int nproma, int ngptot, long long* n);
+int cloudsc2_taylor_sweep_launch(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot, int nproma_stat,
+                                 const cloudsc2_inputs* in, const cloudsc2_outputs* out, const cloudsc2_outputs* tl,
+                                 double* work, double* sums, void* stream);
+
 /* Adjoint-test norms per column (cloudsc_driver_ad_mod.F90:184-195,240-264):
  * norm1 = sum_lev sum_10 y*y, norm2 = sum_lev sum_16 (0.01*x_traj)*x_adj (PSUPSAT term uses x0=0, :139),
  * norm3 = |n1-n2|/eps [/n2].  norms(3, ncols_padded) device doubles; *blockmax (device double) receives

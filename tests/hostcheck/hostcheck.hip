@@ -41,6 +41,12 @@ template <unsigned F> struct HcAd {
   }
 };
 
+template <unsigned F> struct HcTaylor {
+  static void run(long long gthread, const TaylorArgs* a) {
+    if constexpr ((F & ~(C2F_QSAT | C2F_PRECISE | C2F_EVAP | C2F_OFF32)) == 0) taylor_column<F>(gthread, a);
+  }
+};
+
 // same derivation as get_tables() in cloudsc2_kernels.hip
 
 static void hc_tables(const cloudsc2_params& p, LevelTab& tab, Geom& g) {
@@ -148,6 +154,28 @@ int hostcheck_ad(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev
   unsigned f = (in->qsat.ptr ? C2F_QSAT : 0u) | (g_hc_precise ? C2F_PRECISE : 0u) | (a.nl.c.evap ? C2F_EVAP : 0u) |
                (g_hc_off32 ? C2F_OFF32 : 0u) | (g_hc_assign ? C2F_ASSIGN : 0u);
   for (long long gc = 0; gc < a.nl.g.ncols_pad; ++gc) hc_dispatch<HcAd, 64>(f, gc, &a);
+  return 0;
+}
+
+// the lambda sweep of the Taylor test (cloudsc2_taylor_sweep_launch's first kernel): colsum[(10*10 + 10) * ncols_pad]
+int hostcheck_taylor_sweep(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot, const cloudsc2_inputs* in,
+                           const cloudsc2_outputs* out, const cloudsc2_outputs* tl, double* colsum) {
+  TaylorArgs a;
+  a.nl.g = hc_geom(nproma, nlev, ngptot);
+  a.nl.c = hc_consts(*prm, ptsphy);
+  LevelTab tab; hc_tables(*prm, tab, a.nl.g);
+  a.nl.tab = &tab;
+  a.nl.s = Strides{0, 0, 0, 0, 0};
+  hc_in(*in, a.nl.s, a.nl.in); hc_out(*out, a.nl.s, a.nl.out);
+  a.nl.zero_plane = nullptr; a.nl.zero_stride = 0; a.nl.lam = 0; a.nl.ckpt = nullptr;
+  const cloudsc2_field* f[10] = {&tl->tent, &tl->tenq, &tl->tenl, &tl->teni, &tl->clc, &tl->fplsl, &tl->fplsn, &tl->fhpsl, &tl->fhpsn, &tl->covptot};
+  const int half[10] = {0, 0, 0, 0, 0, 1, 1, 1, 1, 0};
+  for (int i = 0; i < 10; ++i) { a.tl.p[i] = f[i]->ptr; a.tl.stride[i] = f[i]->block_stride; a.tl.nlevx[i] = nlev + half[i]; }
+  for (int il = 0; il < kTaylorLambdas; ++il) a.lam[il] = (real_t)pow(10.0, -(double)(il + 1));
+  a.colsum = colsum;
+  unsigned fl = (in->qsat.ptr ? C2F_QSAT : 0u) | (g_hc_precise ? C2F_PRECISE : 0u) | (a.nl.c.evap ? C2F_EVAP : 0u) | (g_hc_off32 ? C2F_OFF32 : 0u);
+  const long long nthreads = ((a.nl.g.ncols_pad + kTaylorCols - 1) / kTaylorCols) * 64;
+  for (long long t = 0; t < nthreads; ++t) hc_dispatch<HcTaylor, 64>(fl, t, &a);
   return 0;
 }
 

@@ -674,3 +674,71 @@ def test_fortran_drivers_through_iso_c_binding():
     assert "TEST PASSED, penalty" in out, out
     out, _ = _run_fortran("dwarf-cloudsc2-ad", 1, 100, 100)
     assert "TEST OK" in out, out
+
+
+@pytest.mark.parametrize("nproma, ngptot, nproma_stat, mode, levapls2", [(128, 1000, 128, 2, False), (32, 333, 32, 1, False),
+                                                                          (100, 250, 100, 2, True), (128, 777, 16, 1, False),
+                                                                          (1, 61, 1, 2, False)])
+def test_lambda_sweep_equals_ten_perturbed_runs(nproma, ngptot, nproma_stat, mode, levapls2):
+    """cloudsc2_taylor_sweep_launch (the ten lambdas on the lanes of a wave, nothing stored) against what it replaces: ten
+    perturbed NL launches that store their outputs, each followed by cloudsc2_taylor_sums_launch
+    (cloudsc_driver_tl_mod.F90:197-244).  Both evaluate the same level function on the same perturbed inputs, so a term
+    F - F5 differs by rounding only; a block's sum is compared against the sum of the terms' magnitudes.  The denominators
+    (sums of the TL outputs) differ by summation order only."""
+    import torch
+
+    from dwarf_p_cloudsc2_tl_ad_amd.state import PLANE_Q, PLANE_QI, PLANE_QL, PLANE_T
+
+    tab = c2.synthetic_table()
+    prm = c2.default_params(c2.ceta_from_table(tab), lregcl=False, levapls2=levapls2)
+    prm.math_mode = mode
+    ds = c2.DeviceState.from_table(tab, nproma, ngptot)
+    ds.satur(prm)
+    ds.nl(prm, fused_satur=False)
+    inc, dout = c2.FlatFields.pair(ds.nb, ds.nlev, ds.nproma, ds.device)
+    # a second set of output arrays for the perturbed runs, laid out like the state's own (what the NL launch requires)
+    from dwarf_p_cloudsc2_tl_ad_amd.driver import _fld
+
+    pc = {n: torch.zeros_like(getattr(ds, n)) for n in ("B_LOC", "PA", "PCOVPTOT", "PFPLSL", "PFPLSN", "PFHPSL", "PFHPSN")}
+    S, H = ds.nproma * ds.nlev, ds.nproma * (ds.nlev + 1)
+    po = B.Outputs()
+    po.tent, po.tenq = _fld(pc["B_LOC"], PLANE_T * S, 8 * S), _fld(pc["B_LOC"], PLANE_Q * S, 8 * S)
+    po.tenl, po.teni = _fld(pc["B_LOC"], PLANE_QL * S, 8 * S), _fld(pc["B_LOC"], PLANE_QI * S, 8 * S)
+    po.clc, po.covptot = _fld(pc["PA"], 0, S), _fld(pc["PCOVPTOT"], 0, S)
+    po.fplsl, po.fplsn = _fld(pc["PFPLSL"], 0, H), _fld(pc["PFPLSN"], 0, H)
+    po.fhpsl, po.fhpsn = _fld(pc["PFHPSL"], 0, H), _fld(pc["PFHPSN"], 0, H)
+    ds.increments(into=inc)
+    ds.tl(prm, inc, dout, store_traj=False)
+    sweep = ds.taylor_sweep(prm, dout, nproma_stat=nproma_stat)
+    torch.cuda.synchronize()
+    assert torch.isfinite(sweep).all()
+    # the ten compared fields in the order of the ERROR_NORM calls (cloudsc_driver_tl_mod.F90:233-242), and their size
+    fields = (("tent", ds.B_LOC[:, PLANE_T]), ("tenq", ds.B_LOC[:, PLANE_Q]), ("tenl", ds.B_LOC[:, PLANE_QL]), ("teni", ds.B_LOC[:, PLANE_QI]),
+              ("clc", ds.PA), ("fplsl", ds.PFPLSL), ("fplsn", ds.PFPLSN), ("fhpsl", ds.PFHPSL), ("fhpsn", ds.PFHPSN), ("covptot", ds.PCOVPTOT))
+    size = [float(t.abs().max()) for _, t in fields]
+    names = [n for n, _ in fields]
+    nbs = (ngptot + nproma_stat - 1) // nproma_stat
+    for il in range(10):
+        lam = 10.0 ** -(il + 1)
+        ds.nl(prm, fused_satur=False, pert_lambda=lam, outputs=po)
+        if nproma_stat == nproma:
+            old = ds.taylor_sums(po, dout, lam)
+            torch.cuda.synchronize()
+            got, ref = sweep[il].cpu().numpy(), old.cpu().numpy()
+            den_tol = 1e-11 * np.abs(ref[:, :, 1]) + 1e-12 * np.abs(ref[:, :, 1]).max(axis=0, keepdims=True) + 1e-300
+            assert np.all(np.abs(got[:, :, 1] - ref[:, :, 1]) <= den_tol), (il, np.abs(got[:, :, 1] - ref[:, :, 1]).max())
+            # numerators: per field, against the magnitude of what is summed (the base field's own size x eps x terms)
+            for f, nm in enumerate(names):
+                scale = size[f] * ds.nlev * nproma
+                assert np.all(np.abs(got[:, f, 0] - ref[:, f, 0]) <= 64 * np.finfo(np.float64).eps * scale + 1e-300), (il, nm)
+        else:
+            torch.cuda.synchronize()
+            # another block of the statistic than the arrays' blocking: the block sums must add up to the same totals
+            old = ds.taylor_sums(po, dout, lam)
+            torch.cuda.synchronize()
+            tot_new, tot_old = sweep[il].sum(dim=0).cpu().numpy(), old.sum(dim=0).cpu().numpy()
+            assert sweep[il].shape[0] == nbs
+            assert np.allclose(tot_new[:, 1], tot_old[:, 1], rtol=1e-10, atol=1e-12 * np.abs(tot_old[:, 1]).max() + 1e-300)
+            for f, nm in enumerate(names):
+                scale = size[f] * ds.nlev * ngptot
+                assert abs(tot_new[f, 0] - tot_old[f, 0]) <= 64 * np.finfo(np.float64).eps * scale + 1e-300, (il, nm)

@@ -260,3 +260,72 @@ def test_perturbed_nl_matches_explicit_perturbation(oracle):
     want = oracle.cloudsc2(st.ptsphy, pin)
     for n, a in refcall.state_outputs_block(got, 0).items():
         assert relerr(want[n], a) <= TOL, n
+
+
+@pytest.mark.parametrize("nproma, ngptot, precise, off32, levapls2", [(8, 14, 0, 0, False), (5, 23, 1, 1, False), (16, 16, 0, 1, True)])
+def test_lambda_sweep_of_the_taylor_test(oracle, nproma, ngptot, precise, off32, levapls2):
+    """taylor_column (the ten lambdas of cloudsc_driver_tl_mod.F90:197-244 on the lanes of a wave: lane (c, k) of wave w runs
+    column 6w + c perturbed by 10^-(k+1), compares with the stored base run level by level and keeps the level sums) against ten
+    explicit perturbed NL sweeps of the same build: the terms are the same operations, the level sums are taken in the same order."""
+    tab = c2.synthetic_table()
+    prm = make_params(tab, levapls2=levapls2)
+    set_lib_params(oracle, prm)
+    hc = hostcheck()
+    hc.hostcheck_set_precise(precise)
+    hc.hostcheck_set_off32(off32)
+    try:
+        st = c2.state_from_table(tab, nproma, ngptot)
+        qsat = oracle_qsat(oracle, st)
+        base = st.copy()
+        i, o = host_traj_blocks(base, qsat)
+        hc.hostcheck_nl(C.byref(prm), st.ptsphy, nproma, st.nlev, ngptot, C.byref(i), C.byref(o), B.Field(), 0.0)
+        rng = np.random.default_rng(5)
+        tl = flat_fields("out", st.nblocks, st.nlev, nproma)
+        for a in tl.values():
+            a[...] = rng.standard_normal(a.shape)
+        for n in ("fplsl", "fplsn", "fhpsl", "fhpsn"):
+            tl[n][:, 0, :] = 0.0  # the fluxes' top value is zero in every run (cloudsc2tl.F90: PFPLSL(JL,1) = 0)
+        tlb = flat_block("out", tl)
+        ncols_pad = st.nblocks * nproma
+        colsum = np.full((110, ncols_pad), np.nan)
+        hc.hostcheck_taylor_sweep(C.byref(prm), st.ptsphy, nproma, st.nlev, ngptot, C.byref(i), C.byref(o), C.byref(tlb),
+                                  colsum.ctypes.data_as(C.c_void_p))
+        names = ("tent", "tenq", "tenl", "teni", "clc", "fplsl", "fplsn", "fhpsl", "fhpsn", "covptot")  # order of the ERROR_NORM calls
+
+        def columns(arrs):  # name -> (levels, all columns) with the fluxes on the half levels below (what a level of the sweep sees)
+            out = {}
+            for n in names:
+                a = arrs[n]
+                a = a[:, 1:, :] if a.shape[1] == st.nlev + 1 else a
+                out[n] = np.ascontiguousarray(a.transpose(1, 0, 2)).reshape(st.nlev, ncols_pad)
+            return out
+
+        def out_arrays(s):
+            return {"tent": s.B_LOC[:, 0], "tenq": s.B_LOC[:, 2], "tenl": s.B_LOC[:, 3], "teni": s.B_LOC[:, 4], "clc": s.PA,
+                    "covptot": s.PCOVPTOT, "fplsl": s.PFPLSL, "fplsn": s.PFPLSN, "fhpsl": s.PFHPSL, "fhpsn": s.PFHPSN}
+
+        b = columns(out_arrays(base))
+        act = np.arange(ncols_pad) < ngptot  # (blocks are contiguous: global column = ibl*nproma + jl)
+        assert np.all(np.isnan(colsum[:, ~act])) and np.all(np.isfinite(colsum[:, act]))
+        tlc = columns(tl)
+        for f, n in enumerate(names):
+            acc = np.zeros(ncols_pad)
+            for jk in range(st.nlev):
+                acc += tlc[n][jk].astype(np.float64)
+            assert np.array_equal(colsum[100 + f, act], acc[act]), n
+        for k in range(10):
+            lam = 10.0 ** -(k + 1)
+            pert = st.copy()
+            ip, op = host_traj_blocks(pert, qsat)
+            hc.hostcheck_nl(C.byref(prm), st.ptsphy, nproma, st.nlev, ngptot, C.byref(ip), C.byref(op), B.Field(), lam)
+            pc = columns(out_arrays(pert))
+            for f, n in enumerate(names):
+                acc = np.zeros(ncols_pad)
+                for jk in range(st.nlev):
+                    acc += (b[n][jk] - pc[n][jk]).astype(np.float64)
+                got = colsum[k * 10 + f, act]
+                scale = np.abs(b[n]).max() * st.nlev
+                assert np.all(np.abs(got - acc[act]) <= 4 * np.finfo(B.REAL).eps * scale), (k, n, np.abs(got - acc[act]).max(), scale)
+    finally:
+        hc.hostcheck_set_precise(0)
+        hc.hostcheck_set_off32(0)
