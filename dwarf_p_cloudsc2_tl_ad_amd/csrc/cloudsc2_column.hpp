@@ -57,6 +57,7 @@ struct NlArgs {
 };
 struct TlArgs {
   Consts c; Geom g; Strides s, sp; InPtrs in; OutPtrs out; InPtrs din; OutPtrs dout; const LevelTab* tab;
+  real_t supsat_inc;  // C2F_SELFINC: the PSUPSAT increment is supsat_inc*PSUPSAT (0.01 in the Taylor test, 0 in the adjoint test)
 };
 // The adjoint's trajectory pass IS the NL sweep (with carry checkpoints, nl.ckpt = the scratch plane), so its
 // argument block embeds the NL one.
@@ -294,6 +295,8 @@ enum : unsigned {
   C2F_PERT = 8u,     // NL only: inputs perturbed by lambda*0.01*x (Taylor test)
   C2F_CKPT = 16u,    // NL only: trajectory pass of the adjoint (carry checkpoints)
   C2F_TRAJ = 8u,     // TL only: trajectory outputs are stored
+  C2F_SELFINC = 16u, // TL only: the increments are 0.01*x of the trajectory inputs themselves, as in both test drivers
+                     // (cloudsc_driver_tl_mod.F90:156-171, cloudsc_driver_ad_mod.F90:124-139): no perturbation inputs are read
   C2F_ASSIGN = 8u,   // AD only: the input adjoints are ASSIGNED (x = A^T y) instead of accumulated (x += A^T y): their old
                      // values are neither read nor needed to be zero (the adjoint test zeroes them first, cloudsc_driver_ad_mod.F90:198-213)
   C2F_OFF32 = 32u,   // every buffer of the launch < 4 GiB: 32-bit byte offsets (LaneOff32)
@@ -592,12 +595,22 @@ C2_HD void taylor_column(long long gthread, TaylorArgsP ta) {
   cs[(long long)(100 + k) * np + gcol] = stl;
 }
 
+// The increments of the reference's test drivers: dx = 0.01*x for every input (ZSUPSAT: 0.01*PSUPSAT in the Taylor test, 0 in the
+// adjoint test), taken from the trajectory inputs the sweep holds anyway.
+C2_HD void self_increment(const RawLevel& r, real_t supsat_inc, RawLevel& d) {
+  const real_t e = RC(0.01);
+  d.paph_k1 = r.paph_k1 * e; d.pap = r.pap * e; d.q = r.q * e; d.qsat = r.qsat * e; d.t = r.t * e; d.l = r.l * e; d.i = r.i * e;
+  d.lude = r.lude * e; d.lu_k1 = r.lu_k1 * e; d.mfu = r.mfu * e; d.mfd = r.mfd * e; d.gt = r.gt * e; d.gq = r.gq * e;
+  d.gl = r.gl * e; d.gi = r.gi * e; d.supsat = r.supsat * supsat_inc;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // TL: SATUR (optionally fused) + CLOUDSC2TL for one column
 // ---------------------------------------------------------------------------------------------------------
 template <unsigned F>
 C2_HD void tl_column(long long gcol, TlArgsP a) {
   constexpr bool HAS_QSAT = (F & C2F_QSAT) != 0, P = (F & C2F_PRECISE) != 0, STORE_TRAJ = (F & C2F_TRAJ) != 0, EVAP = (F & C2F_EVAP) != 0;
+  constexpr bool SELFINC = (F & C2F_SELFINC) != 0;
   typedef typename std::conditional<(F & C2F_OFF32) != 0, unsigned, long long>::type OT;
   LaneOff o, op; bool active;
   if (!lane_setup(&a->g, &a->s, gcol, o, active)) return;
@@ -620,7 +633,7 @@ C2_HD void tl_column(long long gcol, TlArgsP a) {
   real_t paph_surf = RC(0.0), dpaph_surf = RC(0.0);
   if (EVAP) {
     paph_surf = in->paph[o.half + (long long)nlev * nproma];
-    dpaph_surf = din->paph[op.half + (long long)nlev * nproma];
+    dpaph_surf = SELFINC ? paph_surf * RC(0.01) : din->paph[op.half + (long long)nlev * nproma];
   }
 
   if (STORE_TRAJ) store_top(out, o, c);
@@ -629,10 +642,10 @@ C2_HD void tl_column(long long gcol, TlArgsP a) {
   Carry cy; cy.rfl = RC(0.0); cy.sfl = RC(0.0); cy.covptot = RC(0.0);
   Carry dcy; dcy.rfl = RC(0.0); dcy.sfl = RC(0.0); dcy.covptot = RC(0.0);
   RawLevel cur, nxt, dcur, dnxt;
-  real_t paph_k = in->paph[o.half], dpaph_k = din->paph[op.half];
+  real_t paph_k = in->paph[o.half], dpaph_k = SELFINC ? paph_k * RC(0.01) : din->paph[op.half];
   const LaneOffT<OT> ol = lane_off_as<OT>(o), opl = lane_off_as<OT>(op);  // offsets used inside the level loop
   load_level<HAS_QSAT>(in, ol, nproma, nlev, 0, cur);
-  load_level<true>(din, opl, nproma, nlev, 0, dcur);
+  if (!SELFINC) load_level<true>(din, opl, nproma, nlev, 0, dcur);
 
   // Both input sets of level jk+1 are requested at the top of level jk.  Measured alternatives (profiles/r02_ab_experiments.txt):
   // requesting the perturbation inputs at the top of their own level (no second register set for them: 280 instead of 311
@@ -644,12 +657,14 @@ C2_HD void tl_column(long long gcol, TlArgsP a) {
     TlArgsP ap = a;
     C2_LAUNDER(ap);
     in = &ap->in; din = &ap->din;
-    nxt = cur; dnxt = dcur;
+    nxt = cur;
+    if (!SELFINC) dnxt = dcur;
     if (!last) {
       load_level<HAS_QSAT>(in, ol, nproma, nlev, jk + 1, nxt);
-      load_level<true>(din, opl, nproma, nlev, jk + 1, dnxt);
+      if (!SELFINC) load_level<true>(din, opl, nproma, nlev, jk + 1, dnxt);
     }
     if (!HAS_QSAT) cur.qsat = satur_point<P>(c, cur.pap, cur.t);
+    if (SELFINC) self_increment(cur, ap->supsat_inc, dcur);
 
     LevelCst k;
     level_cst(tab, jk, last, k);
@@ -666,7 +681,7 @@ C2_HD void tl_column(long long gcol, TlArgsP a) {
     store_out(dout, opl, nproma, jk, dlo);
     paph_k = cur.paph_k1; dpaph_k = dcur.paph_k1;
     cur = nxt;
-    dcur = dnxt;
+    if (!SELFINC) dcur = dnxt;
   }
 }
 

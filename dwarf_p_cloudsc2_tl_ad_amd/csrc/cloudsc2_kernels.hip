@@ -250,7 +250,7 @@ template <class Args> using KernelFn = void (*)(Args);
   [[maybe_unused]] const std::array<KernelFn<Args>, NF> table = table##_make(std::make_integer_sequence<unsigned, NF>{});
 // (the trajectory pass differs from the plain NL sweep only with the evaporation branch: the cover checkpoint)
 C2_VARIANT_TABLE(g_nl_kernels, nl_kernel, NlArgs, 128, (F & C2F_CKPT) ? ((F & C2F_EVAP) && !(F & (C2F_PERT | C2F_NOLIN))) : true)
-C2_VARIANT_TABLE(g_tl_kernels, tl_kernel, TlArgs, 64, !(F & 16u))
+C2_VARIANT_TABLE(g_tl_kernels, tl_kernel, TlArgs, 64, true)
 C2_VARIANT_TABLE(g_ad_reverse_kernels, ad_reverse_kernel, AdArgs, 64, !(F & 16u))
 C2_VARIANT_TABLE(g_ad_kernels, ad_kernel, AdArgs, 64, C2_AD_FUSED != 0 && !(F & 16u))
 C2_VARIANT_TABLE(g_taylor_kernels, taylor_kernel, TaylorArgs, 64, !(F & (C2F_PERT | C2F_CKPT)))
@@ -726,13 +726,14 @@ int cloudsc2_nl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
   return launch_variant(g_nl_kernels[f], args, g.ncols_pad, (hipStream_t)stream);
 }
 
-int cloudsc2_tl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
-                       const cloudsc2_inputs* traj_in, const cloudsc2_outputs* traj_out,
-                       const cloudsc2_inputs* pert_in, const cloudsc2_outputs* pert_out, void* stream) {
+// pert_in == NULL: the increments are 0.01*x of the trajectory inputs (supsat_inc * PSUPSAT for PSUPSAT), C2F_SELFINC
+static int tl_launch_impl(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
+                          const cloudsc2_inputs* traj_in, const cloudsc2_outputs* traj_out,
+                          const cloudsc2_inputs* pert_in, double supsat_inc, const cloudsc2_outputs* pert_out, void* stream) {
   Geom g;
   int rc = check_geom(prm, nproma, nlev, ngptot, g);
   if (rc) return rc;
-  if (!traj_in || !traj_out || !pert_in || !pert_out) return fail(CLOUDSC2_EINVAL, "NULL argument block");
+  if (!traj_in || !traj_out || !pert_out) return fail(CLOUDSC2_EINVAL, "NULL argument block");
   Strides s = {0, 0, 0, 0, 0}, sp = {0, 0, 0, 0, 0};
   InPtrs ip, dip; OutPtrs op, dop;
   if ((rc = resolve_in(*traj_in, false, s, ip))) return rc;
@@ -743,14 +744,20 @@ int cloudsc2_tl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
   if (nset != 0 && nset != 10) return fail(CLOUDSC2_EINVAL, "traj_out: give all ten trajectory outputs or none");
   const bool store_traj = nset == 10;
   if ((rc = resolve_out(*traj_out, false, s, op))) return rc;
-  if ((rc = resolve_in(*pert_in, true, sp, dip))) return rc;
+  if (pert_in) {
+    if ((rc = resolve_in(*pert_in, true, sp, dip))) return rc;
+  } else {
+    memset(&dip, 0, sizeof(dip));  // (sp: taken from the outputs by resolve_out)
+  }
   if ((rc = resolve_out(*pert_out, true, sp, dop))) return rc;
   const LevelTab* tab;
   if ((rc = get_tables(*prm, &tab, &g.kb0, &g.kb1))) return rc;
   TlArgs args;
   args.c = make_consts(*prm, ptsphy);
   args.g = g; args.s = s; args.sp = sp; args.in = ip; args.out = op; args.din = dip; args.dout = dop; args.tab = tab;
+  args.supsat_inc = (real_t)supsat_inc;
   unsigned f = 0;
+  if (!pert_in) f |= C2F_SELFINC;
   if (traj_in->qsat.ptr) f |= C2F_QSAT;
   if (store_traj) f |= C2F_TRAJ;
   if (precise_of(prm)) f |= C2F_PRECISE;
@@ -761,6 +768,19 @@ int cloudsc2_tl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
   // (profiles/r03_wave_times.txt)
   if (sizeof(real_t) == 4 && (f & C2F_OFF32) && !(f & C2F_EVAP)) args.g.fair = nl_fair(g.ncols_pad, false);
   return launch_variant(g_tl_kernels[f], args, g.ncols_pad, (hipStream_t)stream);
+}
+
+int cloudsc2_tl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
+                       const cloudsc2_inputs* traj_in, const cloudsc2_outputs* traj_out,
+                       const cloudsc2_inputs* pert_in, const cloudsc2_outputs* pert_out, void* stream) {
+  if (!pert_in) return fail(CLOUDSC2_EINVAL, "NULL argument block");
+  return tl_launch_impl(prm, ptsphy, nproma, nlev, ngptot, traj_in, traj_out, pert_in, 0.0, pert_out, stream);
+}
+
+int cloudsc2_tl_launch_self(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
+                            const cloudsc2_inputs* traj_in, const cloudsc2_outputs* traj_out, double supsat_increment,
+                            const cloudsc2_outputs* pert_out, void* stream) {
+  return tl_launch_impl(prm, ptsphy, nproma, nlev, ngptot, traj_in, traj_out, nullptr, supsat_increment, pert_out, stream);
 }
 
 // which == 0: both sweeps (fused kernel, or the two kernels in stream order); 1: forward sweep only; 2: reverse sweep only

@@ -316,11 +316,18 @@ class DeviceState:
         B.check(B.lib.cloudsc2_nl_launch(C.byref(prm), self.ptsphy, self.nproma, self.nlev, self.ngptot, C.byref(i),
                                          C.byref(o), zp, float(pert_lambda), self._stream(stream)))
 
-    def tl(self, prm: B.Params, pert_in: FlatFields, pert_out: FlatFields, stream=None, fused_satur: bool = False,
-           store_traj: bool = True):
+    def tl(self, prm: B.Params, pert_in: FlatFields | None, pert_out: FlatFields, stream=None, fused_satur: bool = False,
+           store_traj: bool = True, supsat_increment: float = 0.01):
+        """CLOUDSC2TL.  pert_in=None: the increments of the reference's test drivers, dx = 0.01*x (supsat_increment*PSUPSAT for
+        PSUPSAT), formed inside the sweep (cloudsc2_tl_launch_self)."""
         i = self.traj_inputs(not fused_satur)
         o = self.traj_outputs() if store_traj else B.Outputs()
-        di, do = pert_in.block(), pert_out.block()
+        do = pert_out.block()
+        if pert_in is None:
+            B.check(B.lib.cloudsc2_tl_launch_self(C.byref(prm), self.ptsphy, self.nproma, self.nlev, self.ngptot, C.byref(i),
+                                                  C.byref(o), float(supsat_increment), C.byref(do), self._stream(stream)))
+            return
+        di = pert_in.block()
         B.check(B.lib.cloudsc2_tl_launch(C.byref(prm), self.ptsphy, self.nproma, self.nlev, self.ngptot, C.byref(i),
                                          C.byref(o), C.byref(di), C.byref(do), self._stream(stream)))
 
@@ -408,9 +415,10 @@ class ResidentState:
         self.nproma, self.nlev, self.ngptot = nproma, nlev, ngptot
 
     def __del__(self):
-        if getattr(self, "h", None) is not None and self.h.value:
-            B.lib.cloudsc2_state_destroy(self.h)
-            self.h = C.c_void_p()
+        lib = getattr(B, "lib", None) if B is not None else None  # (module globals are gone at interpreter shutdown)
+        if lib is not None and getattr(self, "h", None) is not None and self.h.value:
+            lib.cloudsc2_state_destroy(self.h)
+            self.h.value = None
 
     @classmethod
     def from_table(cls, tab: dict, nproma: int, ngptot: int, start: int = 0, period: int | None = None) -> "ResidentState":

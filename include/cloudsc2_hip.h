@@ -164,6 +164,14 @@ int cloudsc2_tl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
                        const cloudsc2_inputs* traj_in, const cloudsc2_outputs* traj_out,
                        const cloudsc2_inputs* pert_in, const cloudsc2_outputs* pert_out, void* stream);
 
+/* CLOUDSC2TL with the increments of the reference's two test drivers, dx = 0.01*x for every input
+ * (cloudsc_driver_tl_mod.F90:156-171; cloudsc_driver_ad_mod.F90:124-139, where ZSUPSAT = 0): they are formed from the
+ * trajectory inputs the sweep reads anyway, so no increment arrays exist (17.5 KB per column less to read, and nothing to
+ * fill first).  supsat_increment: the factor of the PSUPSAT increment (0.01 Taylor test, 0 adjoint test). */
+int cloudsc2_tl_launch_self(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
+                            const cloudsc2_inputs* traj_in, const cloudsc2_outputs* traj_out, double supsat_increment,
+                            const cloudsc2_outputs* pert_out, void* stream);
+
 /* CLOUDSC2AD (src/cloudsc2_ad/cloudsc2ad.F90:10-24): trajectory in -> trajectory out; adj_out holds the
  * output adjoints on entry and is zeroed on return (:917-919,955-966,1173,1572,1678-1691); adj_in is
  * accumulated (+=, :1723-1738) except PSUPSAT which is assigned PTSPHY*zqp1 exactly as the reference does

@@ -28,7 +28,7 @@ template <unsigned F> struct HcNl {
 // only the flag words the launchers can produce are instantiated (TL: QSAT|PRECISE|EVAP|TRAJ|OFF32, AD: no TRAJ)
 template <unsigned F> struct HcTl {
   static void run(long long gc, const TlArgs* a) {
-    if constexpr ((F & ~(C2F_QSAT | C2F_PRECISE | C2F_EVAP | C2F_TRAJ | C2F_OFF32)) == 0) tl_column<F>(gc, a);
+    if constexpr ((F & ~(C2F_QSAT | C2F_PRECISE | C2F_EVAP | C2F_TRAJ | C2F_OFF32 | C2F_SELFINC)) == 0) tl_column<F>(gc, a);
   }
 };
 static int g_hc_ad_sweep = 0;  // 0: both sweeps of the adjoint, 1: forward sweep only, 2: reverse sweep only
@@ -86,12 +86,14 @@ static Geom hc_geom(int nproma, int nlev, int ngptot) {
 static int g_hc_precise = 0;
 static int g_hc_off32 = 0;
 static int g_hc_assign = 0;
+static double g_hc_supsat_inc = -1.0;  // >= 0: hostcheck_tl runs the self-increment form with this PSUPSAT factor
 
 extern "C" {
 
 void hostcheck_set_precise(int p) { g_hc_precise = p; }
 void hostcheck_set_assign(int v) { g_hc_assign = v; }  // AD: assign the input adjoints instead of accumulating (C2F_ASSIGN)
 void hostcheck_set_ad_sweep(int v) { g_hc_ad_sweep = v; }  // what cloudsc2_ad_launch_forward / _reverse run
+void hostcheck_set_self_increment(double v) { g_hc_supsat_inc = v; }  // TL: cloudsc2_tl_launch_self (negative: increments from din)
 void hostcheck_set_off32(int v) { g_hc_off32 = v; }  // 32-bit byte offsets (C2F_OFF32) in all three sweeps
 
 int hostcheck_satur(const cloudsc2_params* prm, int nproma, int nlev, int ngptot, cloudsc2_field pap, cloudsc2_field t,
@@ -129,9 +131,17 @@ int hostcheck_tl(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev
   LevelTab tab; hc_tables(*prm, tab, a.g);
   a.tab = &tab;
   a.s = Strides{0, 0, 0, 0, 0}; a.sp = Strides{0, 0, 0, 0, 0};
-  hc_in(*in, a.s, a.in); hc_out(*out, a.s, a.out); hc_in(*din, a.sp, a.din); hc_out(*dout, a.sp, a.dout);
+  hc_in(*in, a.s, a.in); hc_out(*out, a.s, a.out);
+  if (g_hc_supsat_inc >= 0.0) {  // cloudsc2_tl_launch_self: the increments are 0.01*x, formed in the sweep; din is not read
+    memset(&a.din, 0, sizeof(a.din));
+    a.sp.full = dout->clc.block_stride; a.sp.half = dout->fplsl.block_stride;
+  } else {
+    hc_in(*din, a.sp, a.din);
+  }
+  hc_out(*dout, a.sp, a.dout);
+  a.supsat_inc = (real_t)(g_hc_supsat_inc >= 0.0 ? g_hc_supsat_inc : 0.0);
   unsigned f = (in->qsat.ptr ? C2F_QSAT : 0u) | C2F_TRAJ | (g_hc_precise ? C2F_PRECISE : 0u) | (a.c.evap ? C2F_EVAP : 0u) |
-               (g_hc_off32 ? C2F_OFF32 : 0u);
+               (g_hc_off32 ? C2F_OFF32 : 0u) | (g_hc_supsat_inc >= 0.0 ? C2F_SELFINC : 0u);
   for (long long gc = 0; gc < a.g.ncols_pad; ++gc) hc_dispatch<HcTl, 64>(f, gc, &a);
   return 0;
 }

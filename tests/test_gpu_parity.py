@@ -742,3 +742,33 @@ def test_lambda_sweep_equals_ten_perturbed_runs(nproma, ngptot, nproma_stat, mod
             for f, nm in enumerate(names):
                 scale = size[f] * ds.nlev * ngptot
                 assert abs(tot_new[f, 0] - tot_old[f, 0]) <= 64 * np.finfo(np.float64).eps * scale + 1e-300, (il, nm)
+
+
+@pytest.mark.parametrize("nproma, ngptot, mode, levapls2, sup", [(128, 1000, 1, False, 0.01), (32, 333, 2, False, 0.0), (100, 250, 1, True, 0.01)])
+def test_tl_with_increments_formed_in_the_sweep(nproma, ngptot, mode, levapls2, sup):
+    """cloudsc2_tl_launch_self (dx = 0.01*x formed inside the TL sweep, what both test drivers use) against cloudsc2_tl_launch fed
+    with the same increments from memory (cloudsc_driver_tl_mod.F90:156-171; cloudsc_driver_ad_mod.F90:124-139 with ZSUPSAT = 0).
+    The same operations on the same values; the compiler may contract 0.01*x into a following add, hence a few ulp."""
+    import torch
+
+    tab = c2.synthetic_table()
+    prm = c2.default_params(c2.ceta_from_table(tab), lregcl=False, levapls2=levapls2)
+    prm.math_mode = mode
+    ds = c2.DeviceState.from_table(tab, nproma, ngptot)
+    ds.PSUPSAT.uniform_(0.0, 1e-4)  # (zero in the synthetic table: make the PSUPSAT increment matter)
+    ds.satur(prm)
+    inc, dout = c2.FlatFields.pair(ds.nb, ds.nlev, ds.nproma, ds.device)
+    _, dself = c2.FlatFields.pair(ds.nb, ds.nlev, ds.nproma, ds.device)
+    ds.increments(zero_supsat=(sup == 0.0), into=inc)
+    ds.tl(prm, inc, dout)
+    traj = {n: getattr(ds, n).clone() for n in ("B_LOC", "PA", "PCOVPTOT", "PFPLSL", "PFPLSN", "PFHPSL", "PFHPSN")}
+    ds.tl(prm, None, dself, supsat_increment=sup)
+    torch.cuda.synchronize()
+    for n, t in traj.items():
+        assert torch.equal(getattr(ds, n), t), n  # the trajectory outputs do not depend on where the increments come from
+    for n in B.OUT_NAMES:
+        a, b = dout.t[n], dself.t[n]
+        assert torch.isfinite(b).all()
+        scale = float(a.abs().max())
+        floor = 1e-15 if n in ("clc", "covptot") else 1e-300  # (cover perturbations that are cancellation noise of 1e-18 themselves)
+        assert float((a - b).abs().max()) <= 1e-13 * scale + floor, (n, float((a - b).abs().max()), scale)

@@ -132,6 +132,31 @@ def test_tl_ad_columns(oracle, flags, nlev):
     for n in x:
         assert np.array_equal(x[n], x3[n]), ("off32 ad", n)
 
+    # the self-increment form of the TL sweep (C2F_SELFINC, cloudsc2_tl_launch_self: dx = 0.01*x formed in the sweep, as both test
+    # drivers define it) equals the sweep fed with those increments from memory -- same operations, no contraction on this host build
+    for sup in (0.01, 0.0):
+        hc.hostcheck_set_self_increment(sup)
+        try:
+            got5 = st.copy()
+            i5, o5 = host_traj_blocks(got5, qsat)
+            tl5 = flat_fields("out", nb, nlev, nproma)
+            do5 = flat_block("out", tl5)
+            assert hc.hostcheck_tl(C.byref(prm), st.ptsphy, nproma, nlev, ngptot, C.byref(i5), C.byref(o5), None, C.byref(do5)) == 0
+        finally:
+            hc.hostcheck_set_self_increment(-1.0)
+        if sup == 0.0:
+            inc0 = increments_of(st, qsat, zero_supsat=True)
+            got6 = st.copy()
+            i6, o6 = host_traj_blocks(got6, qsat)
+            tl6 = flat_fields("out", nb, nlev, nproma)
+            di6, do6 = flat_block("in", inc0), flat_block("out", tl6)
+            assert hc.hostcheck_tl(C.byref(prm), st.ptsphy, nproma, nlev, ngptot, C.byref(i6), C.byref(o6), C.byref(di6), C.byref(do6)) == 0
+            want = tl6
+        else:
+            want = tl
+        for n in tl:
+            assert np.array_equal(want[n], tl5[n]), ("self-increment tl", sup, n)
+
     # the assign form of the adjoint (C2F_ASSIGN, cloudsc2_ad_launch_assign): x = A^T y into arrays full of garbage must equal
     # the accumulate form into zeroed arrays bit for bit on the active columns, and must not touch the padded tail
     hc.hostcheck_set_assign(1)
