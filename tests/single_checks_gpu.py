@@ -129,6 +129,53 @@ def gpu_checks():
     except c2.Cloudsc2Error as e:
         print("CLOUDSC_DRIVER_TL fp32 (informative):", e)
 
+    # The TL sweep that forms the test drivers' increments itself (cloudsc2_tl_launch_self) and the Taylor test's lambda sweep
+    # (cloudsc2_taylor_sweep_launch: ten lambdas on the lanes of a wave) in fp32, against the forms they replace
+    tabs = c2.synthetic_table()
+    prms = make_params(tabs, lregcl=False)
+    ds = c2.DeviceState.from_table(tabs, 64, 500)
+    ds.satur(prms)
+    ds.nl(prms, fused_satur=False)
+    inc, dout = c2.FlatFields.pair(ds.nb, ds.nlev, ds.nproma, ds.device)
+    _, dself = c2.FlatFields.pair(ds.nb, ds.nlev, ds.nproma, ds.device)
+    ds.increments(into=inc)
+    ds.tl(prms, inc, dout, store_traj=False)
+    ds.tl(prms, None, dself, store_traj=False)
+    sweep = ds.taylor_sweep(prms, dout)
+    torch.cuda.synchronize()
+    for n in B.OUT_NAMES:
+        a, b = dout.t[n].double(), dself.t[n].double()
+        e = float((a - b).abs().max()) / max(float(a.abs().max()), 1e-300)
+        floor_ok = float((a - b).abs().max()) < 1e-9 and n in ("clc", "covptot")
+        assert e < 2e-5 or floor_ok, ("tl self-increment fp32", n, e)
+    from dwarf_p_cloudsc2_tl_ad_amd.driver import _fld
+    from dwarf_p_cloudsc2_tl_ad_amd.state import PLANE_Q, PLANE_QI, PLANE_QL, PLANE_T
+
+    pc = {n: torch.zeros_like(getattr(ds, n)) for n in ("B_LOC", "PA", "PCOVPTOT", "PFPLSL", "PFPLSN", "PFHPSL", "PFHPSN")}
+    S, H = ds.nproma * ds.nlev, ds.nproma * (ds.nlev + 1)
+    po = B.Outputs()
+    po.tent, po.tenq = _fld(pc["B_LOC"], PLANE_T * S, 8 * S), _fld(pc["B_LOC"], PLANE_Q * S, 8 * S)
+    po.tenl, po.teni = _fld(pc["B_LOC"], PLANE_QL * S, 8 * S), _fld(pc["B_LOC"], PLANE_QI * S, 8 * S)
+    po.clc, po.covptot = _fld(pc["PA"], 0, S), _fld(pc["PCOVPTOT"], 0, S)
+    po.fplsl, po.fplsn = _fld(pc["PFPLSL"], 0, H), _fld(pc["PFPLSN"], 0, H)
+    po.fhpsl, po.fhpsn = _fld(pc["PFHPSL"], 0, H), _fld(pc["PFHPSN"], 0, H)
+    size = [float(t.abs().max()) for t in (ds.B_LOC[:, PLANE_T], ds.B_LOC[:, PLANE_Q], ds.B_LOC[:, PLANE_QL], ds.B_LOC[:, PLANE_QI], ds.PA,
+                                           ds.PFPLSL, ds.PFPLSN, ds.PFHPSL, ds.PFHPSN, ds.PCOVPTOT)]
+    worst = 0.0
+    for il in range(10):
+        lam = 10.0 ** -(il + 1)
+        ds.nl(prms, fused_satur=False, pert_lambda=lam, outputs=po)
+        old = ds.taylor_sums(po, dout, lam)
+        torch.cuda.synchronize()
+        got, ref = sweep[il].cpu().numpy(), old.cpu().numpy()
+        assert np.all(np.abs(got[:, :, 1] - ref[:, :, 1]) <= 1e-5 * np.abs(ref[:, :, 1]) + 1e-6 * np.abs(ref[:, :, 1]).max(axis=0, keepdims=True) + 1e-30), ("lambda sweep fp32: TL sums", il)
+        for f in range(10):
+            bound = 64 * 1.1920928955078125e-07 * size[f] * ds.nlev * ds.nproma + 1e-30
+            d = float(np.abs(got[:, f, 0] - ref[:, f, 0]).max())
+            worst = max(worst, d / bound)
+            assert d <= bound, ("lambda sweep fp32", il, f, d, bound)
+    print(f"fp32 TL with increments formed in the sweep == TL fed with them; lambda sweep == ten perturbed runs (worst {worst:.3f} of the rounding bound)")
+
     # device-side tiling and validation in fp32
     tab = c2.random_table(137, 100, seed=3)
     prm = make_params(tab)
