@@ -121,7 +121,10 @@ def _load() -> C.CDLL:
     lib.cloudsc2_tl_launch.argtypes = [pp, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(Inputs), C.POINTER(Outputs),
                                        C.POINTER(Inputs), C.POINTER(Outputs), C.c_void_p]
     lib.cloudsc2_tl_launch_self.argtypes = [pp, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(Inputs), C.POINTER(Outputs), C.c_double,
-                                            C.POINTER(Outputs), C.c_void_p]
+                                            C.POINTER(Outputs), C.c_void_p, C.c_void_p]
+    lib.cloudsc2_ad_launch_reverse_norms.argtypes = [pp, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(Inputs), C.POINTER(Outputs),
+                                                     C.POINTER(Inputs), C.POINTER(Outputs), C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.cloudsc2_ad_launch_reverse_norms.restype = C.c_int
     lib.cloudsc2_tl_launch_self.restype = C.c_int
     lib.cloudsc2_ad_launch.argtypes = [pp, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(Inputs), C.POINTER(Outputs),
                                        C.POINTER(Inputs), C.POINTER(Outputs), C.c_void_p, C.c_void_p]
@@ -201,7 +204,7 @@ lib = _load()
 EXPORTED = ("cloudsc2_params_default", "cloudsc2_last_error", "cloudsc2_device_available", "cloudsc2_current_device", "cloudsc2_set_math_mode",
             "cloudsc2_get_math_mode", "cloudsc2_real_bytes", "cloudsc2_nl_launch",
             "cloudsc2_satur_launch", "cloudsc2_tl_launch", "cloudsc2_tl_launch_self", "cloudsc2_ad_launch", "cloudsc2_ad_launch_assign",
-            "cloudsc2_ad_launch_forward", "cloudsc2_ad_launch_reverse", "cloudsc2_taylor_sums_launch",
+            "cloudsc2_ad_launch_forward", "cloudsc2_ad_launch_reverse", "cloudsc2_ad_launch_reverse_norms", "cloudsc2_taylor_sums_launch",
             "cloudsc2_taylor_sweep_work_doubles", "cloudsc2_taylor_sweep_launch", "cloudsc2_adjoint_norms_launch", "cloudsc2_nl_run", "cloudsc2_tl_taylor_run", "cloudsc2_ad_symmetry_run",
             "cloudsc2_release_workspace", "cloudsc2_taylor_verdict", "cloudsc2_adjoint_verdict",
             "cloudsc2_expand_launch", "cloudsc2_validate_workspace_doubles", "cloudsc2_validate_launch",

@@ -58,11 +58,14 @@ struct NlArgs {
 struct TlArgs {
   Consts c; Geom g; Strides s, sp; InPtrs in; OutPtrs out; InPtrs din; OutPtrs dout; const LevelTab* tab;
   real_t supsat_inc;  // C2F_SELFINC: the PSUPSAT increment is supsat_inc*PSUPSAT (0.01 in the Taylor test, 0 in the adjoint test)
+  double* yy;         // C2F_SELFINC: NULL, or (ncols_pad) doubles receiving <y,y> of each column's TL outputs (the adjoint test's norm1)
 };
 // The adjoint's trajectory pass IS the NL sweep (with carry checkpoints, nl.ckpt = the scratch plane), so its
 // argument block embeds the NL one.
 struct AdArgs {
   NlArgs nl; Strides sa; InPtrsRW ain; OutPtrs aout;
+  double* norms;  // C2F_ADNORM: (3, ncols_pad) doubles: norm1 (read), norm2 and norm3 (written)
+  double* gmax;   // C2F_ADNORM: one double, raised to the largest |norm3| (the kernel's wave maxima, atomically)
 };
 typedef const C2_CONST_AS NlArgs* NlArgsP;
 typedef const C2_CONST_AS TlArgs* TlArgsP;
@@ -299,6 +302,8 @@ enum : unsigned {
                      // (cloudsc_driver_tl_mod.F90:156-171, cloudsc_driver_ad_mod.F90:124-139): no perturbation inputs are read
   C2F_ASSIGN = 8u,   // AD only: the input adjoints are ASSIGNED (x = A^T y) instead of accumulated (x += A^T y): their old
                      // values are neither read nor needed to be zero (the adjoint test zeroes them first, cloudsc_driver_ad_mod.F90:198-213)
+  C2F_ADNORM = 16u,  // AD reverse sweep, assign form only: the adjoint test's <x, x_adj> and norm3 are formed in the sweep
+                     // (cloudsc_driver_ad_mod.F90:240-264) instead of re-reading the 32 planes afterwards
   C2F_OFF32 = 32u,   // every buffer of the launch < 4 GiB: 32-bit byte offsets (LaneOff32)
   C2F_NOLIN = 64u,   // NL only: .NOT.(LPHYLIN .OR. LDRAIN1D), the FOEALFA / FOEEWM form of stage A (cloudsc2.F90:365-369)
 };
@@ -642,6 +647,7 @@ C2_HD void tl_column(long long gcol, TlArgsP a) {
   Carry cy; cy.rfl = RC(0.0); cy.sfl = RC(0.0); cy.covptot = RC(0.0);
   Carry dcy; dcy.rfl = RC(0.0); dcy.sfl = RC(0.0); dcy.covptot = RC(0.0);
   RawLevel cur, nxt, dcur, dnxt;
+  double yy = 0.0;  // SELFINC: <y,y> of the column (cloudsc_driver_ad_mod.F90:184-195; the fluxes' top values are zero)
   real_t paph_k = in->paph[o.half], dpaph_k = SELFINC ? paph_k * RC(0.01) : din->paph[op.half];
   const LaneOffT<OT> ol = lane_off_as<OT>(o), opl = lane_off_as<OT>(op);  // offsets used inside the level loop
   load_level<HAS_QSAT>(in, ol, nproma, nlev, 0, cur);
@@ -679,9 +685,18 @@ C2_HD void tl_column(long long gcol, TlArgsP a) {
     out = &ap->out; dout = &ap->dout;
     if (STORE_TRAJ) store_out(out, ol, nproma, jk, lo);
     store_out(dout, opl, nproma, jk, dlo);
+    if (SELFINC) {
+      yy += (double)dlo.tent * dlo.tent + (double)dlo.tenq * dlo.tenq + (double)dlo.tenl * dlo.tenl + (double)dlo.teni * dlo.teni +
+            (double)dlo.clc * dlo.clc + (double)dlo.covptot * dlo.covptot + (double)dlo.fplsl * dlo.fplsl + (double)dlo.fplsn * dlo.fplsn +
+            (double)dlo.fhpsl * dlo.fhpsl + (double)dlo.fhpsn * dlo.fhpsn;
+    }
     paph_k = cur.paph_k1; dpaph_k = dcur.paph_k1;
     cur = nxt;
     if (!SELFINC) dcur = dnxt;
+  }
+  if (SELFINC) {
+    double* p = a->yy;
+    if (p) p[gcol] = yy;
   }
 }
 
@@ -773,15 +788,18 @@ C2_HD void ad_load_level(AdArgsP ap, const LaneOffT<OT>& o, const LaneOffT<OT>& 
 }
 
 // reverse sweep (cloudsc2ad.F90:877-1740); the trajectory pass has run before
+C2_HD double adjoint_norm3(double n1, double n2);
+
 template <unsigned F>
-C2_HD void ad_reverse_column(long long gcol, AdArgsP a) {
+C2_HD double ad_reverse_column(long long gcol, AdArgsP a) {  // returns |norm3| of the column with C2F_ADNORM (+inf for NaN), else 0
   constexpr bool HAS_QSAT = (F & C2F_QSAT) != 0, P = (F & C2F_PRECISE) != 0, EVAP = (F & C2F_EVAP) != 0;
-  constexpr bool OFF32 = (F & C2F_OFF32) != 0, ASSIGN = (F & C2F_ASSIGN) != 0;
+  constexpr bool OFF32 = (F & C2F_OFF32) != 0, ASSIGN = (F & C2F_ASSIGN) != 0, ADNORM = (F & C2F_ADNORM) != 0;
+  static_assert(!ADNORM || ASSIGN, "the fused norms are those of the adjoint test: assign form");
   typedef typename std::conditional<OFF32, unsigned, long long>::type OT;
   LaneOff o, oa64; bool active;
-  if (!lane_setup(&a->nl.g, &a->nl.s, gcol, o, active)) return;
+  if (!lane_setup(&a->nl.g, &a->nl.s, gcol, o, active)) return 0.0;
   lane_setup(&a->nl.g, &a->sa, gcol, oa64, active);
-  if (!active) return;
+  if (!active) return 0.0;
   const int nlev = a->nl.g.nlev, nproma = a->nl.g.nproma;
   LevelTabP tab = (LevelTabP)a->nl.tab;
   ConstsP c = C2_CONSTS(&a->nl);
@@ -803,6 +821,7 @@ C2_HD void ad_reverse_column(long long gcol, AdArgsP a) {
   real_t paph_pending = RC(0.0);  // contribution of level jk+1 to the PAPHP1 adjoint at half level jk+1
   real_t surf_acc = RC(0.0);      // PAPHP1(KLEV+1) adjoint, written once at the end
   real_t paph_k1 = paph_bottom;
+  double n2 = 0.0;  // ADNORM: <x0, x_adj>, x0 = 0.01 * trajectory inputs, ZSUPSAT0 = 0 (cloudsc_driver_ad_mod.F90:139,240-256)
   AdLevelLoads L;
   for (int jk = nlev - 1; jk >= 0; --jk) {
     const bool last = (jk == nlev - 1);
@@ -857,6 +876,14 @@ C2_HD void ad_reverse_column(long long gcol, AdArgsP a) {
     } else {
       stg(px.paph, oa.half + d1, xo.paph_k1 + (ax.paph_k1 + paph_pending));
     }
+    if (ADNORM) {  // (assign form: what has just been stored is ax itself)
+      const double e = 0.01;
+      n2 += ((double)cur.pap * e) * ax.pap + ((double)cur.q * e) * ax.q + ((double)cur.qsat * e) * ax.qs + ((double)cur.t * e) * ax.t +
+            ((double)cur.l * e) * ax.l + ((double)cur.i * e) * ax.i + ((double)cur.lude * e) * ax.lude + ((double)cur.mfu * e) * ax.mfu +
+            ((double)cur.mfd * e) * ax.mfd + ((double)cur.gt * e) * ax.gt + ((double)cur.gq * e) * ax.gq + ((double)cur.gl * e) * ax.gl +
+            ((double)cur.gi * e) * ax.gi;
+      if (!last) n2 += ((double)cur.lu_k1 * e) * ax.lu_k1 + ((double)cur.paph_k1 * e) * (ax.paph_k1 + paph_pending);
+    }
     paph_pending = ax.paph_k;
 
     // output adjoints are consumed (cloudsc2ad.F90:917-919,955-966,1173,1572)
@@ -888,6 +915,19 @@ C2_HD void ad_reverse_column(long long gcol, AdArgsP a) {
   aout->fplsn[oa64.half] = RC(0.0);
   aout->fhpsl[oa64.half] = RC(0.0);
   aout->fhpsn[oa64.half] = RC(0.0);
+  if (ADNORM) {
+    // the two half levels the loop does not store: PAPHP1(1) (paph_k1 now holds the trajectory's value there) and PAPHP1(KLEV+1)
+    n2 += ((double)paph_k1 * 0.01) * paph_pending + ((double)paph_bottom * 0.01) * surf_acc;
+    double* norms = a->norms;
+    const long long np = a->nl.g.ncols_pad;
+    double n3 = adjoint_norm3(norms[gcol], n2);
+    norms[np + gcol] = n2;
+    norms[2 * np + gcol] = n3;
+    n3 = fabs(n3);
+    if (!(n3 == n3)) n3 = (double)INFINITY;  // NaN counts as failure
+    return n3;
+  }
+  return 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------------------

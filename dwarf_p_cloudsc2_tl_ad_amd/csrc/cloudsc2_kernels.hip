@@ -218,10 +218,19 @@ tl_kernel(TlArgs args) {
 #endif
 #endif
 constexpr long long kAdSplitBelow = 400000;
+__device__ __forceinline__ double wave_max(double v);
+__device__ __forceinline__ void atomic_max_pos(double* addr, double v);
 template <unsigned F>
 __global__ void C2_BOUNDS(C2_AD_WAVES) ad_reverse_kernel(AdArgs args) {
   C2_KERNEL_BODY(C2_WAVE_LOG_BEGIN);
-  C2_KERNEL_BODY((ad_reverse_column<F>(global_column(), kernarg<AdArgs>())));
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr ((F & C2F_ADNORM) != 0) {  // the adjoint test's norms formed in the sweep: the wave's largest |norm3| joins the global one
+    const double m = wave_max(ad_reverse_column<F>(global_column(), kernarg<AdArgs>()));
+    if ((threadIdx.x & 63) == 0) atomic_max_pos(kernarg<AdArgs>()->gmax, m);
+  } else {
+    ad_reverse_column<F>(global_column(), kernarg<AdArgs>());
+  }
+#endif
   C2_KERNEL_BODY(C2_WAVE_LOG_END);
 }
 template <unsigned F>
@@ -251,8 +260,8 @@ template <class Args> using KernelFn = void (*)(Args);
 // (the trajectory pass differs from the plain NL sweep only with the evaporation branch: the cover checkpoint)
 C2_VARIANT_TABLE(g_nl_kernels, nl_kernel, NlArgs, 128, (F & C2F_CKPT) ? ((F & C2F_EVAP) && !(F & (C2F_PERT | C2F_NOLIN))) : true)
 C2_VARIANT_TABLE(g_tl_kernels, tl_kernel, TlArgs, 64, true)
-C2_VARIANT_TABLE(g_ad_reverse_kernels, ad_reverse_kernel, AdArgs, 64, !(F & 16u))
-C2_VARIANT_TABLE(g_ad_kernels, ad_kernel, AdArgs, 64, C2_AD_FUSED != 0 && !(F & 16u))
+C2_VARIANT_TABLE(g_ad_reverse_kernels, ad_reverse_kernel, AdArgs, 64, !(F & C2F_ADNORM) || ((F & C2F_ASSIGN) && !(F & C2F_EVAP)))
+C2_VARIANT_TABLE(g_ad_kernels, ad_kernel, AdArgs, 64, C2_AD_FUSED != 0 && !(F & C2F_ADNORM))
 C2_VARIANT_TABLE(g_taylor_kernels, taylor_kernel, TaylorArgs, 64, !(F & (C2F_PERT | C2F_CKPT)))
 
 // ---------------------------------------------------------------------------------------------------------
@@ -729,7 +738,8 @@ int cloudsc2_nl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
 // pert_in == NULL: the increments are 0.01*x of the trajectory inputs (supsat_inc * PSUPSAT for PSUPSAT), C2F_SELFINC
 static int tl_launch_impl(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
                           const cloudsc2_inputs* traj_in, const cloudsc2_outputs* traj_out,
-                          const cloudsc2_inputs* pert_in, double supsat_inc, const cloudsc2_outputs* pert_out, void* stream) {
+                          const cloudsc2_inputs* pert_in, double supsat_inc, const cloudsc2_outputs* pert_out, double* yy,
+                          void* stream) {
   Geom g;
   int rc = check_geom(prm, nproma, nlev, ngptot, g);
   if (rc) return rc;
@@ -756,6 +766,7 @@ static int tl_launch_impl(const cloudsc2_params* prm, double ptsphy, int nproma,
   args.c = make_consts(*prm, ptsphy);
   args.g = g; args.s = s; args.sp = sp; args.in = ip; args.out = op; args.din = dip; args.dout = dop; args.tab = tab;
   args.supsat_inc = (real_t)supsat_inc;
+  args.yy = yy;
   unsigned f = 0;
   if (!pert_in) f |= C2F_SELFINC;
   if (traj_in->qsat.ptr) f |= C2F_QSAT;
@@ -774,20 +785,20 @@ int cloudsc2_tl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
                        const cloudsc2_inputs* traj_in, const cloudsc2_outputs* traj_out,
                        const cloudsc2_inputs* pert_in, const cloudsc2_outputs* pert_out, void* stream) {
   if (!pert_in) return fail(CLOUDSC2_EINVAL, "NULL argument block");
-  return tl_launch_impl(prm, ptsphy, nproma, nlev, ngptot, traj_in, traj_out, pert_in, 0.0, pert_out, stream);
+  return tl_launch_impl(prm, ptsphy, nproma, nlev, ngptot, traj_in, traj_out, pert_in, 0.0, pert_out, nullptr, stream);
 }
 
 int cloudsc2_tl_launch_self(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
                             const cloudsc2_inputs* traj_in, const cloudsc2_outputs* traj_out, double supsat_increment,
-                            const cloudsc2_outputs* pert_out, void* stream) {
-  return tl_launch_impl(prm, ptsphy, nproma, nlev, ngptot, traj_in, traj_out, nullptr, supsat_increment, pert_out, stream);
+                            const cloudsc2_outputs* pert_out, double* yy, void* stream) {
+  return tl_launch_impl(prm, ptsphy, nproma, nlev, ngptot, traj_in, traj_out, nullptr, supsat_increment, pert_out, yy, stream);
 }
 
 // which == 0: both sweeps (fused kernel, or the two kernels in stream order); 1: forward sweep only; 2: reverse sweep only
 static int ad_launch_impl(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
                           const cloudsc2_inputs* traj_in, const cloudsc2_outputs* traj_out,
                           const cloudsc2_inputs* adj_in, const cloudsc2_outputs* adj_out, cloudsc2_real* scratch,
-                          void* stream, bool assign, int which = 0) {
+                          void* stream, bool assign, int which = 0, double* norms = nullptr, double* gmax = nullptr) {
   Geom g;
   int rc = check_geom(prm, nproma, nlev, ngptot, g);
   if (rc) return rc;
@@ -821,6 +832,11 @@ static int ad_launch_impl(const cloudsc2_params* prm, double ptsphy, int nproma,
   if (precise_of(prm)) f |= C2F_PRECISE;
   if (args.nl.c.evap) f |= C2F_EVAP;
   if (assign) f |= C2F_ASSIGN;
+  if (norms) {  // the adjoint test's norm2 / norm3 formed in the reverse sweep
+    if (which != 2 || !assign || args.nl.c.evap || !gmax) return fail(CLOUDSC2_EINVAL, "fused adjoint norms: reverse sweep alone, assign form, no evaporation branch");
+    f |= C2F_ADNORM;
+    args.norms = norms; args.gmax = gmax;
+  }
   if (fits_off32(g, nproma, nlev, {s.full, s.half, s.cml, s.clv, s.loc, sa.full, sa.half, sa.cml, sa.clv, sa.loc,
                                   (long long)nproma * nlev /* scratch */})) f |= C2F_OFF32;
   // the trajectory pass as a kernel of its own: the NL sweep, with the cover checkpoint when the evaporation branch is on
@@ -860,6 +876,14 @@ int cloudsc2_ad_launch_reverse(const cloudsc2_params* prm, double ptsphy, int np
                                int assign, void* stream) {
   return ad_launch_impl(prm, ptsphy, nproma, nlev, ngptot, traj_in, traj_out, adj_in, adj_out, const_cast<cloudsc2_real*>(scratch),
                         stream, assign != 0, 2);
+}
+
+int cloudsc2_ad_launch_reverse_norms(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
+                                     const cloudsc2_inputs* traj_in, const cloudsc2_outputs* traj_out,
+                                     const cloudsc2_inputs* adj_in, const cloudsc2_outputs* adj_out,
+                                     double* norms, double* blockmax, void* stream) {
+  if (!norms || !blockmax) return fail(CLOUDSC2_EINVAL, "NULL argument");
+  return ad_launch_impl(prm, ptsphy, nproma, nlev, ngptot, traj_in, traj_out, adj_in, adj_out, nullptr, stream, true, 2, norms, blockmax);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -317,15 +317,17 @@ class DeviceState:
                                          C.byref(o), zp, float(pert_lambda), self._stream(stream)))
 
     def tl(self, prm: B.Params, pert_in: FlatFields | None, pert_out: FlatFields, stream=None, fused_satur: bool = False,
-           store_traj: bool = True, supsat_increment: float = 0.01):
+           store_traj: bool = True, supsat_increment: float = 0.01, yy=None):
         """CLOUDSC2TL.  pert_in=None: the increments of the reference's test drivers, dx = 0.01*x (supsat_increment*PSUPSAT for
-        PSUPSAT), formed inside the sweep (cloudsc2_tl_launch_self)."""
+        PSUPSAT), formed inside the sweep (cloudsc2_tl_launch_self); yy: a float64 tensor of NBLOCKS*NPROMA elements receiving <y,y>
+        of every active column then (the adjoint test's norm1)."""
         i = self.traj_inputs(not fused_satur)
         o = self.traj_outputs() if store_traj else B.Outputs()
         do = pert_out.block()
         if pert_in is None:
             B.check(B.lib.cloudsc2_tl_launch_self(C.byref(prm), self.ptsphy, self.nproma, self.nlev, self.ngptot, C.byref(i),
-                                                  C.byref(o), float(supsat_increment), C.byref(do), self._stream(stream)))
+                                                  C.byref(o), float(supsat_increment), C.byref(do),
+                                                  C.c_void_p(yy.data_ptr() if yy is not None else None), self._stream(stream)))
             return
         di = pert_in.block()
         B.check(B.lib.cloudsc2_tl_launch(C.byref(prm), self.ptsphy, self.nproma, self.nlev, self.ngptot, C.byref(i),
@@ -352,6 +354,25 @@ class DeviceState:
             raise ValueError(sweep)
         fn = B.lib.cloudsc2_ad_launch_assign if assign else B.lib.cloudsc2_ad_launch
         B.check(fn(*geom, C.byref(ai), C.byref(ao), sc, self._stream(stream)))
+
+    def adjoint_norms(self, y: FlatFields | None, x_adj: FlatFields | None, norms, blockmax, stream=None):
+        """cloudsc2_adjoint_norms_launch: norm1 = <y,y> (y given) and / or norm2, norm3 (x_adj given) per column into norms(3, columns)."""
+        i = self.traj_inputs(True)
+        q = i.qsat
+        yb = y.block() if y is not None else None
+        xb = x_adj.block() if x_adj is not None else None
+        B.check(B.lib.cloudsc2_adjoint_norms_launch(self.nproma, self.nlev, self.ngptot, C.byref(i) if xb is not None else None,
+                                                    C.byref(q) if xb is not None else None, C.byref(yb) if yb is not None else None,
+                                                    C.byref(xb) if xb is not None else None, C.c_void_p(norms.data_ptr()),
+                                                    C.c_void_p(blockmax.data_ptr()), self._stream(stream)))
+
+    def ad_reverse_norms(self, prm: B.Params, adj_in: FlatFields, adj_out: FlatFields, norms, blockmax, stream=None, fused_satur: bool = False):
+        """The adjoint test's AD leg with norm2 / norm3 formed in the reverse sweep (cloudsc2_ad_launch_reverse_norms)."""
+        i, o = self.traj_inputs(not fused_satur), self.traj_outputs()
+        ai, ao = adj_in.block(), adj_out.block()
+        B.check(B.lib.cloudsc2_ad_launch_reverse_norms(C.byref(prm), self.ptsphy, self.nproma, self.nlev, self.ngptot, C.byref(i), C.byref(o),
+                                                       C.byref(ai), C.byref(ao), C.c_void_p(norms.data_ptr()), C.c_void_p(blockmax.data_ptr()),
+                                                       self._stream(stream)))
 
     def taylor_sums(self, pert_outputs: B.Outputs, tl_out: FlatFields, lam: float, stream=None):
         """ERROR_NORM sums of ONE lambda from perturbed outputs in memory (cloudsc2_taylor_sums_launch): (NBLOCKS, 10, 2) doubles."""

@@ -167,10 +167,12 @@ int cloudsc2_tl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
 /* CLOUDSC2TL with the increments of the reference's two test drivers, dx = 0.01*x for every input
  * (cloudsc_driver_tl_mod.F90:156-171; cloudsc_driver_ad_mod.F90:124-139, where ZSUPSAT = 0): they are formed from the
  * trajectory inputs the sweep reads anyway, so no increment arrays exist (17.5 KB per column less to read, and nothing to
- * fill first).  supsat_increment: the factor of the PSUPSAT increment (0.01 Taylor test, 0 adjoint test). */
+ * fill first).  supsat_increment: the factor of the PSUPSAT increment (0.01 Taylor test, 0 adjoint test).
+ * yy: NULL, or NBLOCKS*NPROMA device doubles receiving <y,y> of each active column's TL outputs -- the adjoint test's norm1
+ * (cloudsc_driver_ad_mod.F90:184-195), formed while the outputs are in registers. */
 int cloudsc2_tl_launch_self(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
                             const cloudsc2_inputs* traj_in, const cloudsc2_outputs* traj_out, double supsat_increment,
-                            const cloudsc2_outputs* pert_out, void* stream);
+                            const cloudsc2_outputs* pert_out, double* yy, void* stream);
 
 /* CLOUDSC2AD (src/cloudsc2_ad/cloudsc2ad.F90:10-24): trajectory in -> trajectory out; adj_out holds the
  * output adjoints on entry and is zeroed on return (:917-919,955-966,1173,1572,1678-1691); adj_in is
@@ -207,6 +209,18 @@ int cloudsc2_ad_launch_reverse(const cloudsc2_params* prm, double ptsphy, int np
                                const cloudsc2_inputs* traj_in, const cloudsc2_outputs* traj_out,
                                const cloudsc2_inputs* adj_in, const cloudsc2_outputs* adj_out,
                                const cloudsc2_real* scratch, int assign, void* stream);
+
+/* The AD leg of the adjoint test with its norms formed in the sweep (cloudsc_driver_ad_mod.F90:198-267): the reverse sweep alone
+ * in the assign form (zeroed input adjoints + CLOUDSC2AD), and for every active column norm2 = <x0, x_adj> with x0 = 0.01 * the
+ * trajectory inputs (ZSUPSAT0 = 0, :139,240-256) and norm3 = |norm1 - norm2| / EPSILON(1._8) [/ norm2] (:258-264), taken while
+ * x_adj is in registers instead of re-reading 32 planes.  norms(3, NBLOCKS*NPROMA) device doubles: row 0 = norm1 on entry
+ * (cloudsc2_tl_launch_self's yy, or cloudsc2_adjoint_norms_launch's first half), rows 1-2 written; *blockmax (device double,
+ * zero or an earlier maximum on entry) is raised to the largest |norm3| (NaN counts as +inf).  Not with LEVAPLS2 / LDRAIN1D
+ * (the reverse sweep alone lacks the cover checkpoints: cloudsc2_ad_launch_assign + cloudsc2_adjoint_norms_launch then). */
+int cloudsc2_ad_launch_reverse_norms(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
+                                     const cloudsc2_inputs* traj_in, const cloudsc2_outputs* traj_out,
+                                     const cloudsc2_inputs* adj_in, const cloudsc2_outputs* adj_out,
+                                     double* norms, double* blockmax, void* stream);
 
 /* Taylor-test statistics for one lambda (ERROR_NORM, cloudsc_driver_tl_mod.F90:21-31, calls :233-244):
  * for each NPROMA block and each of the 10 output fields, sums over the block's active columns and all

@@ -32,11 +32,14 @@ template <unsigned F> struct HcTl {
   }
 };
 static int g_hc_ad_sweep = 0;  // 0: both sweeps of the adjoint, 1: forward sweep only, 2: reverse sweep only
+static double g_hc_norm3_max = 0.0;  // largest |norm3| the C2F_ADNORM sweep returned (what the kernel's wave maxima feed)
 template <unsigned F> struct HcAd {
   static void run(long long gc, const AdArgs* a) {
     if constexpr ((F & ~(C2F_QSAT | C2F_PRECISE | C2F_EVAP | C2F_OFF32 | C2F_ASSIGN)) == 0) {
       if (g_hc_ad_sweep != 2) nl_column<(F & ~C2F_ASSIGN) | C2F_CKPT>(gc, &a->nl);
       if (g_hc_ad_sweep != 1) ad_reverse_column<F>(gc, a);
+    } else if constexpr ((F & C2F_ADNORM) && (F & C2F_ASSIGN) && !(F & C2F_EVAP)) {  // cloudsc2_ad_launch_reverse_norms
+      g_hc_norm3_max = fmax(g_hc_norm3_max, ad_reverse_column<F>(gc, a));
     }
   }
 };
@@ -86,6 +89,8 @@ static Geom hc_geom(int nproma, int nlev, int ngptot) {
 static int g_hc_precise = 0;
 static int g_hc_off32 = 0;
 static int g_hc_assign = 0;
+static double* g_hc_yy = nullptr;      // TL self-increment form: receives <y,y> per column
+static double* g_hc_ad_norms = nullptr;  // AD: (3, ncols_pad), row 0 = norm1; reverse sweep alone in the assign form with the norms formed in it
 static double g_hc_supsat_inc = -1.0;  // >= 0: hostcheck_tl runs the self-increment form with this PSUPSAT factor
 
 extern "C" {
@@ -94,6 +99,9 @@ void hostcheck_set_precise(int p) { g_hc_precise = p; }
 void hostcheck_set_assign(int v) { g_hc_assign = v; }  // AD: assign the input adjoints instead of accumulating (C2F_ASSIGN)
 void hostcheck_set_ad_sweep(int v) { g_hc_ad_sweep = v; }  // what cloudsc2_ad_launch_forward / _reverse run
 void hostcheck_set_self_increment(double v) { g_hc_supsat_inc = v; }  // TL: cloudsc2_tl_launch_self (negative: increments from din)
+void hostcheck_set_yy(double* p) { g_hc_yy = p; }
+void hostcheck_set_ad_norms(double* p) { g_hc_ad_norms = p; g_hc_norm3_max = 0.0; }
+double hostcheck_get_norm3_max(void) { return g_hc_norm3_max; }
 void hostcheck_set_off32(int v) { g_hc_off32 = v; }  // 32-bit byte offsets (C2F_OFF32) in all three sweeps
 
 int hostcheck_satur(const cloudsc2_params* prm, int nproma, int nlev, int ngptot, cloudsc2_field pap, cloudsc2_field t,
@@ -140,6 +148,7 @@ int hostcheck_tl(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev
   }
   hc_out(*dout, a.sp, a.dout);
   a.supsat_inc = (real_t)(g_hc_supsat_inc >= 0.0 ? g_hc_supsat_inc : 0.0);
+  a.yy = g_hc_yy;
   unsigned f = (in->qsat.ptr ? C2F_QSAT : 0u) | C2F_TRAJ | (g_hc_precise ? C2F_PRECISE : 0u) | (a.c.evap ? C2F_EVAP : 0u) |
                (g_hc_off32 ? C2F_OFF32 : 0u) | (g_hc_supsat_inc >= 0.0 ? C2F_SELFINC : 0u);
   for (long long gc = 0; gc < a.g.ncols_pad; ++gc) hc_dispatch<HcTl, 64>(f, gc, &a);
@@ -163,6 +172,11 @@ int hostcheck_ad(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev
   a.nl.zero_plane = nullptr; a.nl.zero_stride = 0; a.nl.lam = 0.0; a.nl.ckpt = scratch;
   unsigned f = (in->qsat.ptr ? C2F_QSAT : 0u) | (g_hc_precise ? C2F_PRECISE : 0u) | (a.nl.c.evap ? C2F_EVAP : 0u) |
                (g_hc_off32 ? C2F_OFF32 : 0u) | (g_hc_assign ? C2F_ASSIGN : 0u);
+  a.norms = g_hc_ad_norms; a.gmax = nullptr;
+  if (g_hc_ad_norms) {
+    if (g_hc_ad_sweep != 2 || !g_hc_assign || a.nl.c.evap) return -1;
+    f |= C2F_ADNORM;
+  }
   for (long long gc = 0; gc < a.nl.g.ncols_pad; ++gc) hc_dispatch<HcAd, 64>(f, gc, &a);
   return 0;
 }

@@ -772,3 +772,45 @@ def test_tl_with_increments_formed_in_the_sweep(nproma, ngptot, mode, levapls2, 
         scale = float(a.abs().max())
         floor = 1e-15 if n in ("clc", "covptot") else 1e-300  # (cover perturbations that are cancellation noise of 1e-18 themselves)
         assert float((a - b).abs().max()) <= 1e-13 * scale + floor, (n, float((a - b).abs().max()), scale)
+
+
+@pytest.mark.parametrize("nproma, ngptot, mode", [(128, 1000, 1), (32, 333, 2), (100, 250, 1)])
+def test_adjoint_norms_formed_in_the_sweeps(nproma, ngptot, mode):
+    """The adjoint test's norms as its driver now forms them -- <y,y> in the TL sweep (cloudsc2_tl_launch_self's yy), <x0,x_adj> and
+    norm3 in the reverse sweep (cloudsc2_ad_launch_reverse_norms) -- against cloudsc2_adjoint_norms_launch over the stored arrays
+    (cloudsc_driver_ad_mod.F90:184-195,240-264)."""
+    import torch
+
+    tab = c2.synthetic_table()
+    prm = c2.default_params(c2.ceta_from_table(tab), lregcl=True)
+    prm.math_mode = mode
+    ds = c2.DeviceState.from_table(tab, nproma, ngptot)
+    ds.satur(prm)
+    x, y = c2.FlatFields.pair(ds.nb, ds.nlev, ds.nproma, ds.device)
+    ncp = ds.nb * ds.nproma
+    f64 = dict(dtype=torch.float64, device=ds.device)
+    na, nb_ = torch.zeros((3, ncp), **f64), torch.zeros((3, ncp), **f64)
+    ga, gb = torch.zeros(1, **f64), torch.zeros(1, **f64)
+    act = torch.arange(ncp, device=ds.device) < ngptot
+
+    ds.tl(prm, None, y, supsat_increment=0.0, yy=na)
+    ds.adjoint_norms(y, None, nb_, gb)
+    ds.ad_reverse_norms(prm, x, y, na, ga)
+    torch.cuda.synchronize()
+    xa = {n: t.clone() for n, t in x.t.items()}
+    assert all(float(t.abs().max()) == 0.0 for t in y.t.values())  # the output adjoints are consumed
+
+    ds.tl(prm, None, y, supsat_increment=0.0)
+    ds.ad(prm, x, y, None, assign=True, sweep="reverse")
+    ds.adjoint_norms(None, x, nb_, gb)
+    torch.cuda.synchronize()
+    for n, t in x.t.items():
+        scale = float(t.abs().max())
+        assert float((t - xa[n]).abs().max()) <= 1e-13 * scale, n
+    a, b = na[:, act].cpu().numpy(), nb_[:, act].cpu().numpy()
+    assert np.allclose(a[0], b[0], rtol=1e-13, atol=0)
+    assert np.allclose(a[1], b[1], rtol=1e-12, atol=0), np.abs(a[1] / b[1] - 1).max()
+    eps = np.finfo(np.float64).eps
+    assert np.array_equal(a[2], np.abs(a[0] - a[1]) / eps / a[1])
+    assert float(ga) == np.abs(a[2]).max() and float(gb) == np.abs(b[2]).max()
+    assert float(ga) < 1e4 and float(gb) < 1e4

@@ -354,3 +354,57 @@ def test_lambda_sweep_of_the_taylor_test(oracle, nproma, ngptot, precise, off32,
     finally:
         hc.hostcheck_set_precise(0)
         hc.hostcheck_set_off32(0)
+
+
+def test_adjoint_test_norms_formed_in_the_sweeps(oracle):
+    """The adjoint test's three norms (cloudsc_driver_ad_mod.F90:184-195,240-264) as the library's driver forms them: <y,y> in the
+    TL sweep that produces y (cloudsc2_tl_launch_self's yy), <x0,x_adj> and norm3 in the reverse sweep that produces x_adj
+    (cloudsc2_ad_launch_reverse_norms) -- against the sums over the stored arrays."""
+    tab = c2.synthetic_table()
+    prm = make_params(tab, lregcl=True)
+    set_lib_params(oracle, prm)
+    nproma, ngptot = 16, 40
+    st = c2.state_from_table(tab, nproma, ngptot)
+    nb, nlev = st.nblocks, st.nlev
+    qsat = oracle_qsat(oracle, st)
+    hc = hostcheck()
+    ncols_pad = nb * nproma
+    norms = np.full((3, ncols_pad), np.nan)
+    got = st.copy()
+    i, o = host_traj_blocks(got, qsat)
+    y = flat_fields("out", nb, nlev, nproma)
+    x = {n: np.full_like(a, 3.5) for n, a in flat_fields("in", nb, nlev, nproma).items()}
+    try:
+        hc.hostcheck_set_self_increment(0.0)
+        hc.hostcheck_set_yy(norms[0].ctypes.data_as(C.c_void_p))
+        yb = flat_block("out", y)
+        assert hc.hostcheck_tl(C.byref(prm), st.ptsphy, nproma, nlev, ngptot, C.byref(i), C.byref(o), None, C.byref(yb)) == 0
+        ysaved = {n: a.copy() for n, a in y.items()}
+        hc.hostcheck_set_ad_sweep(2)
+        hc.hostcheck_set_assign(1)
+        hc.hostcheck_set_ad_norms(norms.ctypes.data_as(C.c_void_p))
+        xb = flat_block("in", x)
+        assert hc.hostcheck_ad(C.byref(prm), st.ptsphy, nproma, nlev, ngptot, C.byref(i), C.byref(o), C.byref(xb), C.byref(yb), None) == 0
+        n3max = hc.hostcheck_get_norm3_max()
+    finally:
+        hc.hostcheck_set_self_increment(-1.0)
+        hc.hostcheck_set_yy(None)
+        hc.hostcheck_set_ad_sweep(0)
+        hc.hostcheck_set_assign(0)
+        hc.hostcheck_set_ad_norms(None)
+    act = (np.arange(ncols_pad) < ngptot)
+
+    def cols(a):  # (blocks, levels, nproma) -> (levels, all columns)
+        return np.ascontiguousarray(a.transpose(1, 0, 2)).reshape(a.shape[1], ncols_pad).astype(np.float64)
+
+    n1 = sum((cols(a) ** 2).sum(axis=0) for a in ysaved.values())
+    assert np.all(np.isnan(norms[:, ~act]))
+    assert np.allclose(norms[0, act], n1[act], rtol=1e-13, atol=0)
+    x0 = increments_of(st, qsat, zero_supsat=True)
+    n2 = sum((cols(x0[n]) * cols(x[n])).sum(axis=0) for n in x if n != "supsat")
+    assert np.allclose(norms[1, act], n2[act], rtol=1e-12, atol=0), np.abs(norms[1, act] / n2[act] - 1).max()
+    eps = np.finfo(np.float64).eps
+    n3 = np.abs(norms[0] - norms[1]) / eps / norms[1]
+    assert np.array_equal(norms[2, act], n3[act])
+    assert n3max == np.abs(n3[act]).max()
+    assert n3max < 1e4  # the adjoint identity itself (cloudsc_driver_ad_mod.F90:289)

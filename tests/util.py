@@ -48,6 +48,9 @@ def hostcheck():
         lib.hostcheck_ad.argtypes = [pp, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(B.Inputs), C.POINTER(B.Outputs),
                                      C.POINTER(B.Inputs), C.POINTER(B.Outputs), C.c_void_p]
         lib.hostcheck_set_self_increment.argtypes = [C.c_double]
+        lib.hostcheck_set_yy.argtypes = [C.c_void_p]
+        lib.hostcheck_set_ad_norms.argtypes = [C.c_void_p]
+        lib.hostcheck_get_norm3_max.restype = C.c_double
         lib.hostcheck_taylor_sweep.argtypes = [pp, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(B.Inputs), C.POINTER(B.Outputs),
                                                C.POINTER(B.Outputs), C.c_void_p]
         _hc = lib

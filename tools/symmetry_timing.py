@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Device time of the adjoint test (cloudsc2_state_ad_symmetry: SATUR, increments, TL, norm 1, AD, norms 2-3) on a resident
-state, with the AD leg as the reverse sweep alone (what the library does) and as CLOUDSC2AD's two sweeps
-(CLOUDSC2_AD_SYMMETRY_FULL=1, measurements only).     python tools/symmetry_timing.py NGPTOT [NPROMA]"""
+"""Device time of the adjoint test (cloudsc2_state_ad_symmetry) on a resident state: as the library runs it (`fused`: SATUR, the TL
+sweep that forms its increments and <y,y>, the reverse sweep alone in its assign form that forms <x0,x_adj> and norm3) and as the
+plain sequence (`unfused`, CLOUDSC2_AD_SYMMETRY_FULL=1, measurements only: TL, norm-1 kernel, CLOUDSC2AD's two sweeps, norm-2/3
+kernel).     python tools/symmetry_timing.py NGPTOT [NPROMA]"""
 import json
 import os
 import sys
@@ -17,7 +18,7 @@ tab = c2.synthetic_table()
 prm = c2.default_params(c2.ceta_from_table(tab), lregcl=True)
 rs = c2.ResidentState.from_table(tab, nproma, ngptot)
 out = {"ngptot": ngptot, "nproma": nproma}
-for label, env in (("reverse_only", "0"), ("both_sweeps", "1"), ("reverse_only_again", "0")):
+for label, env in (("fused", "0"), ("unfused", "1"), ("fused_again", "0")):
     os.environ["CLOUDSC2_AD_SYMMETRY_FULL"] = env
     ms, zn = [], None
     for _ in range(8):
@@ -25,5 +26,5 @@ for label, env in (("reverse_only", "0"), ("both_sweeps", "1"), ("reverse_only_a
         assert ok, zn
         ms.append(t)
     out[label] = {"kernel_ms_median": float(np.median(ms[2:])), "znormg_eps": zn}
-out["whole_test_speedup"] = out["both_sweeps"]["kernel_ms_median"] / out["reverse_only"]["kernel_ms_median"]
+out["whole_test_speedup"] = out["unfused"]["kernel_ms_median"] / out["fused"]["kernel_ms_median"]
 print(json.dumps(out))
