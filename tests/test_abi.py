@@ -72,6 +72,20 @@ def test_compute_entry_points_fail_loudly_without_a_gpu():
             c2.run_state(prm, st, which)
         assert e.value.code == B.CLOUDSC2_ENODEVICE
         assert "no CPU path" in str(e.value)
+    # kernel-level entry points (host pointers are never dereferenced: the device check comes first)
+    i, o = B.Inputs(), B.Outputs()
+    dummy = C.c_void_p(8)
+    launches = {
+        "cloudsc2_nl_launch": lambda: B.lib.cloudsc2_nl_launch(C.byref(prm), 3600.0, 32, prm.nlev, 64, C.byref(i), C.byref(o), B.Field(), 0.0, None),
+        "cloudsc2_tl_launch_self": lambda: B.lib.cloudsc2_tl_launch_self(C.byref(prm), 3600.0, 32, prm.nlev, 64, C.byref(i), C.byref(o), 0.01, C.byref(o), None, None),
+        "cloudsc2_ad_launch_reverse_norms": lambda: B.lib.cloudsc2_ad_launch_reverse_norms(C.byref(prm), 3600.0, 32, prm.nlev, 64, C.byref(i), C.byref(o),
+                                                                                          C.byref(i), C.byref(o), dummy, dummy, None),
+        "cloudsc2_taylor_sweep_launch": lambda: B.lib.cloudsc2_taylor_sweep_launch(C.byref(prm), 3600.0, 32, prm.nlev, 64, 32, C.byref(i), C.byref(o),
+                                                                                  C.byref(o), dummy, dummy, None),
+    }
+    for name, call in launches.items():
+        assert call() == B.CLOUDSC2_ENODEVICE, name
+        assert b"no CPU path" in B.lib.cloudsc2_last_error(), name
 
 
 def test_state_layout_and_tiling():
