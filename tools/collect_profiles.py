@@ -44,8 +44,11 @@ for form in ("adassign", "adreverse", "adreverseassign"):  # the adjoint's other
         if os.path.exists(f) and os.path.getsize(f):
             d = json.load(open(f))
             out[f"{form}_{n}"] = {"ms_per_step": d["ms_per_step"], "value": d["value"], "dtype": d["dtype"], "roofline": d["roofline"]}
-for n in (16384, 160000):
+for n in (16384, 160000, 1048576):
     f = os.path.join(src, f"symmetry_{n}.json")
     if os.path.exists(f) and os.path.getsize(f):
         out[f"adjoint_test_{n}"] = json.load(open(f))
+f = os.path.join(src, "taylor_test.jsonl")
+if os.path.exists(f) and os.path.getsize(f):
+    out["taylor_test"] = [json.loads(line) for line in open(f) if line.strip()]
 json.dump(out, open(os.path.join(dst, f"{prefix}_bench_all_kernels.json"), "w"), indent=1)

@@ -32,4 +32,6 @@ for n in 16384 160000 1048576; do for form in "adassign:--ad-assign" "adreverse:
   timeout -k 10 300 python bench.py --kernel ad ${form#*:} --ngptot $n --steps 30 --warmup 3 --no-cpu-baseline --no-companions > $out/bench_${form%%:*}_$n.json 2>/dev/null
   python -c "import json; d=json.load(open('$out/bench_${form%%:*}_$n.json')); r=d['roofline']; print('${form%%:*} $n', round(r['kernel_ms_avg'],3), r['bytes_per_column'], round(r['frac'],3))"
 done; done
-for n in 16384 160000; do timeout -k 10 300 python tools/symmetry_timing.py $n > $out/symmetry_$n.json 2>/dev/null && cat $out/symmetry_$n.json; done
+for n in 16384 160000 1048576; do timeout -k 10 300 python tools/symmetry_timing.py $n > $out/symmetry_$n.json 2>/dev/null && cat $out/symmetry_$n.json; done
+# the whole Taylor test (SATUR, NL, TL, the lambda sweep, block sums) in precise and in fast arithmetic
+for m in 2 1; do timeout -k 10 300 python tools/taylor_ab.py $m >> $out/taylor_test.jsonl 2>/dev/null; done; cat $out/taylor_test.jsonl
