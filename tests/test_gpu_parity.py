@@ -814,3 +814,17 @@ def test_adjoint_norms_formed_in_the_sweeps(nproma, ngptot, mode):
     assert np.array_equal(a[2], np.abs(a[0] - a[1]) / eps / a[1])
     assert float(ga) == np.abs(a[2]).max() and float(gb) == np.abs(b[2]).max()
     assert float(ga) < 1e4 and float(gb) < 1e4
+
+
+@pytest.mark.parametrize("flags, full", [(dict(lregcl=True, levapls2=True), "0"), (dict(lregcl=True), "1"), (dict(lregcl=True), "0")])
+def test_adjoint_test_driver_in_both_sequences(flags, full, monkeypatch):
+    """cloudsc2_ad_symmetry_run's two sequences: the fused one (TL forming <y,y>, reverse sweep forming the other norms) and the plain
+    one -- TL, norm-1 kernel, both sweeps of CLOUDSC2AD, norm-2/3 kernel -- which the evaporation branch requires (its cover checkpoints
+    come from the forward sweep) and CLOUDSC2_AD_SYMMETRY_FULL=1 selects for measurements.  The identity must hold in all of them."""
+    monkeypatch.setenv("CLOUDSC2_AD_SYMMETRY_FULL", full)
+    tab = c2.random_table(137, 100, seed=11) if flags.get("levapls2") else c2.synthetic_table()
+    prm = c2.default_params(c2.ceta_from_table(tab), **flags)
+    st = c2.state_from_table(tab, 64, 300)
+    zad, ok, _ = c2.run_state(prm, st, "ad")
+    assert np.isfinite(zad) and ok, (flags, full, zad)
+    assert zad * np.finfo(np.float64).eps < 1e-12, zad
