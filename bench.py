@@ -12,8 +12,9 @@ not search.  `roofline.unplaced_first_allocation`
 is the same measurement in a fresh process with the placement switched off.
 
 The line also carries `cpu_baseline` (the reference on the host cores, rank 0 at N=1) and, at N=1, from child processes run
-after the measurement: `companion_kernels` (the same bench for TL and AD -- BASELINE.json's metric names all three) and
-`target_config` (NL at 1 048 576 columns, north_star's target); none of them is inside the timed region.
+after the measurement: `companion_kernels` (the same bench for TL and AD -- BASELINE.json's metric names all three),
+`target_config` (NL at 1 048 576 columns, north_star's target) and `self_tests` (the Taylor test and the adjoint test on a resident
+state of the same size: verdicts and kernel time); none of them is inside the timed region.
 """
 from __future__ import annotations
 
@@ -290,6 +291,9 @@ def main():
                     help="--kernel ad: reverse = the reverse sweep alone (cloudsc2_ad_launch_reverse) on the PFPLSL5 / PFPLSN5 an earlier "
                          "sweep left in the state -- the adjoint leg of cloudsc2_ad_symmetry_run")
     ap.add_argument("--levapls2", action="store_true", help="switch the evaporation branch on (off in every shipped config)")
+    ap.add_argument("--self-tests", action="store_true",
+                    help="no bench line: the reference's two self-tests (CLOUDSC_DRIVER_TL's Taylor test, CLOUDSC_DRIVER_AD's adjoint test) on "
+                         "a resident state of --ngptot columns, with their verdicts and the kernel time of the whole driver call")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="no GPU work: start the ranks, rendezvous, shard the columns, reduce fake verdict norms, print the line "
                          "(CPU rehearsal of the launch path; tests/test_bench_launch.py)")
@@ -320,6 +324,23 @@ def main():
         variant += ", assign form of the adjoint"
     if args.ad_sweep == "reverse" and args.kernel == "ad":
         variant += ", reverse sweep alone"
+
+    if args.self_tests:
+        if not c2.device_available():
+            raise SystemExit("bench.py needs a HIP device: the CLOUDSC2 engine has no CPU path")
+        tab = c2.synthetic_table()
+        ceta = c2.ceta_from_table(tab)
+        rs = c2.ResidentState.from_table(tab, args.nproma, args.ngptot)
+        res = {"ngptot": args.ngptot, "nproma": args.nproma, "dtype": "f32" if single else "f64"}
+        t = [rs.tl_taylor(c2.default_params(ceta, lregcl=False)) for _ in range(4)]  # (precise arithmetic: the Taylor driver's default)
+        res["taylor_test"] = {"kernel_ms": min(x[3] for x in t[1:]), "passed": bool(t[-1][1]), "penalty": int(t[-1][2]),
+                              "ratios": [float(z) for z in t[-1][0]],
+                              "what": "SATUR, TL sweep storing the base trajectory, the ten lambdas in one sweep on the lanes of a wave, block sums"}
+        a = [rs.ad_symmetry(c2.default_params(ceta, lregcl=True)) for _ in range(4)]
+        res["adjoint_test"] = {"kernel_ms": min(x[2] for x in a[1:]), "passed": bool(a[-1][1]), "znormg_in_eps": float(a[-1][0]),
+                               "what": "SATUR, TL sweep forming <y,y>, reverse sweep alone (assign form) forming <x0,x_adj> and norm3"}
+        print(json.dumps(res), flush=True)
+        return
 
     if args.rendezvous_only:
         rank, local, world = c2dist.init_process_group("gloo")
@@ -493,6 +514,11 @@ def main():
                                                             "note": "fresh process, CLOUDSC2_PLACE=0: plain first hipMalloc"}
         except Exception as e:  # noqa: BLE001
             out["roofline"]["unplaced_first_allocation"] = {"error": repr(e)}
+        # (4) the reference's two self-tests on a resident state of the same size: verdicts and the kernel time of the whole driver call
+        try:
+            out["self_tests"] = child_bench(["--self-tests", "--ngptot", args.ngptot, "--nproma", args.nproma, "--precision", args.precision])
+        except Exception as e:  # noqa: BLE001
+            out["self_tests"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.kernel == "nl":
         cb = cpu_baseline(tab, prm, 32, args.ngptot)
         if cb:
