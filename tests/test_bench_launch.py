@@ -94,3 +94,5 @@ def test_without_a_gpu_the_bench_fails_loudly():
         pytest.skip("a GPU is present")
     r = _run(["--steps", 1, "--warmup", 0, "--no-cpu-baseline", "--no-companions"])
     assert r.returncode != 0 and "no CPU path" in (r.stderr + r.stdout)
+    r = _run(["--self-tests", "--ngptot", 100])  # the two self-tests on a resident state: the same refusal
+    assert r.returncode != 0 and "no CPU path" in (r.stderr + r.stdout)
