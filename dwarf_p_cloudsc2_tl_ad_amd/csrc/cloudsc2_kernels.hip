@@ -242,10 +242,18 @@ __global__ void C2_BOUNDS(C2_AD_WAVES) ad_kernel(AdArgs args) {
 }
 
 // The ten perturbed NL runs of the Taylor test in one sweep, the lambdas on the lanes (taylor_column): the grid is over THREADS,
-// 64 per kTaylorCols columns.
+// 64 per kTaylorCols columns.  A wave reads 6 columns = 48 bytes of every 128-byte line it touches, so two or three consecutive
+// waves share each line -- the one sweep whose workgroups share data.  Blocks are dealt round-robin over the 8 XCDs (b and b + 8
+// share one, each XCD with its own L2): consecutive LOGICAL blocks are therefore mapped to physical blocks 8 apart, so that the
+// waves sharing a line sit on one XCD and its L2 fetches the line once (the grid is a multiple of 8 blocks; logical blocks past the
+// end find no column and leave).  Measured (rocprofv3 --pmc FETCH_SIZE, 160 000 columns): see profiles/r03_taylor_sweep_ab.txt.
 template <unsigned F>
 __global__ void __launch_bounds__(kBlock) taylor_kernel(TaylorArgs args) {
-  C2_KERNEL_BODY((taylor_column<F>(global_column(), kernarg<TaylorArgs>())));
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned per_xcd = gridDim.x >> 3;
+  const long long block = (long long)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  taylor_column<F>(block * blockDim.x + threadIdx.x, kernarg<TaylorArgs>());
+#endif
 }
 
 // Variant tables: kernel<F> for every valid flag combination F, indexed by F (see C2F_* in cloudsc2_column.hpp).
@@ -1008,7 +1016,8 @@ int cloudsc2_taylor_sweep_launch(const cloudsc2_params* prm, double ptsphy, int 
   if (args.nl.c.evap) f |= C2F_EVAP;
   if (fits_off32(g, nproma, nlev, {s.full, s.half, s.cml, s.clv, s.loc})) f |= C2F_OFF32;
   const long long nwaves = (g.ncols_pad + kTaylorCols - 1) / kTaylorCols;
-  if ((rc = launch_variant(g_taylor_kernels[f], args, nwaves * 64, (hipStream_t)stream))) return rc;
+  const long long per8 = 8LL * kBlock;  // the kernel's XCD mapping wants a multiple of 8 blocks
+  if ((rc = launch_variant(g_taylor_kernels[f], args, (nwaves * 64 + per8 - 1) / per8 * per8, (hipStream_t)stream))) return rc;
   const long long nblocks_stat = ((long long)ngptot + nproma_stat - 1) / nproma_stat;
   hipLaunchKernelGGL(taylor_reduce_kernel, dim3((unsigned)nblocks_stat), dim3(128), 0, (hipStream_t)stream, nproma_stat, ngptot,
                      g.ncols_pad, nblocks_stat, lam, (const double*)work, sums);
