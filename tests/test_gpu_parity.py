@@ -828,3 +828,41 @@ def test_adjoint_test_driver_in_both_sequences(flags, full, monkeypatch):
     zad, ok, _ = c2.run_state(prm, st, "ad")
     assert np.isfinite(zad) and ok, (flags, full, zad)
     assert zad * np.finfo(np.float64).eps < 1e-12, zad
+
+
+@pytest.mark.parametrize("nproma, ngptot", [(16, 80), (50, 130), (128, 300)])
+def test_test_drivers_against_the_reference_drivers_run_here(nproma, ngptot):
+    """The reference's own CLOUDSC_DRIVER_TL and CLOUDSC_DRIVER_AD (oracle/_ref, compiled from the reference's sources) run on this
+    box on the same state, at blockings and sizes other than the golden file's: the ten Taylor ratios agree where they are not
+    finite-difference noise (lambda >= 1e-6) and the verdict with its penalty is the same; the adjoint test passes in both with a
+    maximum error of a few epsilon."""
+    import re
+    import sys
+
+    if not refcall.have_ref():
+        pytest.skip("needs oracle/_ref (the reference drivers) on the box")
+
+    def capture_stdout(fn):
+        sys.stdout.flush()
+        return refcall.RefLib._capture(1, fn)
+    tab = c2.synthetic_table()
+    ref = refcall.RefLib()
+    prm = c2.default_params(c2.ceta_from_table(tab), lregcl=False)
+    set_lib_params(ref, prm)
+    st = c2.state_from_table(tab, nproma, ngptot)
+    txt = capture_stdout(lambda: ref.driver(1, 1, nproma, st.nlev, ngptot, st.ptsphy, st.driver_arrays()))
+    want = np.array([float(m.group(1)) for m in re.finditer(r"^\s*\d+\s+([0-9.Ee+-]+)\s*$", txt, flags=re.M)][:10])
+    verdict = re.search(r"TEST (PASSED|FAILLED).*", txt).group(0).strip()
+    zn, ok, itest, _ = c2.run_state(prm, c2.state_from_table(tab, nproma, ngptot), "tl")
+    assert want.shape == (10,), txt
+    assert np.allclose(zn[:6], want[:6], rtol=1e-6, atol=0), (zn, want)
+    assert ok == verdict.startswith("TEST PASSED") and verdict.endswith(str(itest)), (verdict, ok, itest)
+
+    prm = c2.default_params(c2.ceta_from_table(tab), lregcl=True)
+    set_lib_params(ref, prm)
+    st = c2.state_from_table(tab, nproma, ngptot)
+    txt = capture_stdout(lambda: ref.driver(2, 1, nproma, st.nlev, ngptot, st.ptsphy, st.driver_arrays()))
+    err = float(re.search(r"maximum error is\s+([0-9.Ee+-]+)", txt).group(1))
+    zad, ok, _ = c2.run_state(prm, c2.state_from_table(tab, nproma, ngptot), "ad")
+    assert "TEST OK" in txt and ok
+    assert err < 100 and zad < 100, (err, zad)  # both a few epsilon (the reference's threshold is 1e4)
