@@ -469,6 +469,34 @@ __global__ void __launch_bounds__(128) taylor_reduce_kernel(int nproma, int ngpt
   o[1] = r1 * lam.v[il];
 }
 
+// The same for LARGE blocks of the statistic (one thread per value would walk thousands of columns one after the other): one
+// workgroup per (block, value), its threads stride the block's columns, fixed-order reduction (wave shuffles, one LDS stage) --
+// deterministic as well.  blockIdx.y < 100: sum(F - F5) of (lambda, field) = blockIdx.y; 100..109: sum(TL) of field blockIdx.y - 100,
+// written once per lambda with its factor.
+__global__ void __launch_bounds__(256) taylor_reduce_wide_kernel(int nproma, int ngptot, long long ncols_pad, long long nblocks, TenLambdas lam,
+                                                                 const double* colsum, double* sums) {
+  const long long ibl = blockIdx.x;
+  const int t = blockIdx.y;
+  const long long c0 = ibl * nproma;
+  const int icend = (int)min((long long)nproma, (long long)ngptot - c0);
+  const double* src = colsum + (long long)t * ncols_pad + c0;
+  double r = 0.0;
+  for (int j = threadIdx.x; j < icend; j += blockDim.x) r += src[j];
+  r = wave_sum(r);
+  __shared__ double red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = r;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  r = (red[0] + red[1]) + (red[2] + red[3]);
+  if (t < 10 * kTaylorLambdas) {
+    const int il = t / 10, f = t - 10 * il;
+    sums[(((long long)il * nblocks + ibl) * 10 + f) * 2 + 0] = r;
+  } else {
+    const int f = t - 10 * kTaylorLambdas;
+    for (int il = 0; il < kTaylorLambdas; ++il) sums[(((long long)il * nblocks + ibl) * 10 + f) * 2 + 1] = r * lam.v[il];
+  }
+}
+
 __device__ __forceinline__ void atomic_max_pos(double* addr, double v) {
   // v >= 0: the IEEE bit pattern of non-negative doubles orders like unsigned integers
   atomicMax((unsigned long long*)addr, (unsigned long long)__double_as_longlong(v));
@@ -1019,8 +1047,13 @@ int cloudsc2_taylor_sweep_launch(const cloudsc2_params* prm, double ptsphy, int 
   const long long per8 = 8LL * kBlock;  // the kernel's XCD mapping wants a multiple of 8 blocks
   if ((rc = launch_variant(g_taylor_kernels[f], args, (nwaves * 64 + per8 - 1) / per8 * per8, (hipStream_t)stream))) return rc;
   const long long nblocks_stat = ((long long)ngptot + nproma_stat - 1) / nproma_stat;
-  hipLaunchKernelGGL(taylor_reduce_kernel, dim3((unsigned)nblocks_stat), dim3(128), 0, (hipStream_t)stream, nproma_stat, ngptot,
-                     g.ncols_pad, nblocks_stat, lam, (const double*)work, sums);
+  if (nproma_stat <= 512) {
+    hipLaunchKernelGGL(taylor_reduce_kernel, dim3((unsigned)nblocks_stat), dim3(128), 0, (hipStream_t)stream, nproma_stat, ngptot,
+                       g.ncols_pad, nblocks_stat, lam, (const double*)work, sums);
+  } else {
+    hipLaunchKernelGGL(taylor_reduce_wide_kernel, dim3((unsigned)nblocks_stat, 10 * kTaylorLambdas + 10), dim3(256), 0, (hipStream_t)stream,
+                       nproma_stat, ngptot, g.ncols_pad, nblocks_stat, lam, (const double*)work, sums);
+  }
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -678,7 +678,8 @@ def test_fortran_drivers_through_iso_c_binding():
 
 @pytest.mark.parametrize("nproma, ngptot, nproma_stat, mode, levapls2", [(128, 1000, 128, 2, False), (32, 333, 32, 1, False),
                                                                           (100, 250, 100, 2, True), (128, 777, 16, 1, False),
-                                                                          (1, 61, 1, 2, False)])
+                                                                          (1, 61, 1, 2, False), (128, 3000, 1300, 1, False),
+                                                                          (2048, 2500, 2048, 1, False)])
 def test_lambda_sweep_equals_ten_perturbed_runs(nproma, ngptot, nproma_stat, mode, levapls2):
     """cloudsc2_taylor_sweep_launch (the ten lambdas on the lanes of a wave, nothing stored) against what it replaces: ten
     perturbed NL launches that store their outputs, each followed by cloudsc2_taylor_sums_launch
