@@ -1,6 +1,7 @@
 // cloudsc2_column.hpp -- what one GPU lane does for its grid column: the 137-level sweeps of SATUR+CLOUDSC2,
-// CLOUDSC2TL and CLOUDSC2AD built from the per-level functions of cloudsc2_level.hpp.  The __global__ kernels in
-// cloudsc2_kernels.hip are thin wrappers (gcol = blockIdx*blockDim + threadIdx) around these functions.
+// CLOUDSC2TL and CLOUDSC2AD built from the per-level functions of cloudsc2_level.hpp, and the Taylor test's lambda loop as one
+// sweep (taylor_column: lane = (column, lambda)).  The __global__ kernels in cloudsc2_kernels.hip are thin wrappers
+// (gcol = blockIdx*blockDim + threadIdx) around these functions.
 //
 // Memory access: lane g reads f[jl + NPROMA*(jk + NLEVx*ibl)] with g = ibl*NPROMA + jl, i.e. consecutive lanes
 // read consecutive doubles of every plane -> a wave64 fetches 512 contiguous bytes per plane and level.  Inputs of
