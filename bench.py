@@ -69,6 +69,33 @@ def select_pmc_traffic(pdir, kernel, ngptot, real_bytes, algorithmic_bytes):
     return traffic, info
 
 
+def roofline_fractions(kernel_ms, ngptot, bytes_per_column, kernel_only_bytes_per_column=None, traffic_bytes=None, peak_gbs=HBM_PEAK_GBS):
+    """The fractions of the HBM peak one launch of `kernel_ms` reaches, in every byte convention the line carries:
+      frac               algorithmic bytes of what the launch moves (NL: 28 536 B/column at NLEV 137, i.e. with the driver's
+                         CLD(:,:,NCLV)=0 plane the launch really writes -- the PMC write bytes agree);
+      frac_kernel_only   NL only: BASELINE.md section 2 / SURVEY 8d's first figure, 27 440 B/column, the CLOUDSC2 dummies alone;
+      frac_actual_bytes  the HBM bytes the counters saw (rocprofv3 FETCH_SIZE + WRITE_SIZE of the committed PMC pass) over the same
+                         time -- for the adjoint 1.2 x the algorithmic bytes (the reverse sweep re-reads the trajectory planes), so
+                         0.57 algorithmic is 0.68 of the peak in bytes actually moved.
+    Pure arithmetic (tests/test_bench_launch.py)."""
+    t = kernel_ms * 1e-3
+    ach = bytes_per_column * ngptot / t / 1e9
+    out = {"achieved": ach, "frac": ach / peak_gbs}
+    if kernel_only_bytes_per_column is not None:
+        out["bytes_per_column_kernel_only"] = int(kernel_only_bytes_per_column)
+        out["frac_kernel_only"] = kernel_only_bytes_per_column * ngptot / t / 1e9 / peak_gbs
+    out["frac_actual_bytes"] = (traffic_bytes / t / 1e9 / peak_gbs) if traffic_bytes else None
+    return out
+
+
+def budgets(budget_s):
+    """The two deadlines of an N-rank run from ONE figure: the whole launch must end (or be killed with a record) inside `budget_s`,
+    a rendezvous or collective that gets no answer fails after a fraction of it.  Environment overrides stay for tests."""
+    launch = float(os.environ.get("CLOUDSC2_BENCH_DEADLINE_S", budget_s))
+    coll = float(os.environ.get("CLOUDSC2_DIST_TIMEOUT_S", max(5.0, min(120.0, budget_s / 3.5))))
+    return launch, coll
+
+
 def effective_cores() -> int:
     """CPU share of this process: cgroup quota if one is set, else the affinity mask."""
     n = len(os.sched_getaffinity(0))
@@ -186,7 +213,7 @@ def _tail(path, n=2000):
         return ""
 
 
-def spawn_ranks(ngpus: int, argv, rehearsal: bool = False) -> int:
+def spawn_ranks(ngpus: int, argv, rehearsal: bool = False, budget_s: float = 420.0) -> int:
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) of this same script and
     relay rank 0's JSON line.  Runs before anything in this process has touched the GPU; the children get
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* exactly as `python -m torch.distributed.run --nproc-per-node N` would set
@@ -207,8 +234,10 @@ def spawn_ranks(ngpus: int, argv, rehearsal: bool = False) -> int:
             return 2
     logdir = os.environ.get("CLOUDSC2_BENCH_LOGDIR") or tempfile.mkdtemp(prefix="cloudsc2_bench_")
     os.makedirs(logdir, exist_ok=True)
-    deadline = time.monotonic() + float(os.environ.get("CLOUDSC2_BENCH_DEADLINE_S", "1500"))
+    launch_s, coll_s = budgets(budget_s)
+    deadline = time.monotonic() + launch_s
     env = dict(os.environ, WORLD_SIZE=str(ngpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), LOCAL_WORLD_SIZE=str(ngpus))
+    env.setdefault("CLOUDSC2_DIST_TIMEOUT_S", str(coll_s))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL needs it)
     procs, errs = [], []
     out0 = os.path.join(logdir, "bench_rank0.out")
@@ -240,13 +269,13 @@ def spawn_ranks(ngpus: int, argv, rehearsal: bool = False) -> int:
         if all(rc == 0 for rc in rcs):
             break
         if time.monotonic() > deadline:
-            failed, why = [(r, None) for r, rc in enumerate(rcs) if rc is None], "still running at the deadline (CLOUDSC2_BENCH_DEADLINE_S)"
+            failed, why = [(r, None) for r, rc in enumerate(rcs) if rc is None], f"still running at the deadline ({launch_s:g} s: --budget-s / CLOUDSC2_BENCH_DEADLINE_S)"
             break
         time.sleep(0.2)
     if failed:
         stop_all()
     lines = [ln for ln in _tail(out0, 1 << 20).splitlines() if ln.strip().startswith("{")]
-    if lines:
+    if lines:  # the last line rank 0 got out: the full one, or the timing line of a run whose verdict legs never finished
         print(lines[-1], flush=True)
     if failed or not lines:
         print(f"bench.py: launch of {ngpus} ranks failed -- (rank, exit code) {failed}: {why}; per-rank stderr in {logdir}", file=sys.stderr)
@@ -294,6 +323,10 @@ def main():
     ap.add_argument("--self-tests", action="store_true",
                     help="no bench line: the reference's two self-tests (CLOUDSC_DRIVER_TL's Taylor test, CLOUDSC_DRIVER_AD's adjoint test) on "
                          "a resident state of --ngptot columns, with their verdicts and the kernel time of the whole driver call")
+    ap.add_argument("--budget-s", type=float, default=420.0,
+                    help="N > 1: everything must be over inside this many seconds (the driver kills a run at 600 s and then nothing is "
+                         "written): the launcher's overall deadline, and -- a fraction of it, at most 120 s -- the timeout of the "
+                         "rendezvous and of every collective.  CLOUDSC2_BENCH_DEADLINE_S / CLOUDSC2_DIST_TIMEOUT_S override")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="no GPU work: start the ranks, rendezvous, shard the columns, reduce fake verdict norms, print the line "
                          "(CPU rehearsal of the launch path; tests/test_bench_launch.py)")
@@ -303,10 +336,15 @@ def main():
         raise SystemExit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ:
         if args.gpus > 1:  # no launcher: become one (nothing here has touched the GPU yet)
-            raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:], rehearsal=args.rendezvous_only))
+            raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:], rehearsal=args.rendezvous_only, budget_s=args.budget_s))
     elif int(os.environ["WORLD_SIZE"]) != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
 
+    # under any launcher (ours or torch.distributed.run): the collectives' timeout follows the budget unless the environment says otherwise
+    os.environ.setdefault("CLOUDSC2_DIST_TIMEOUT_S", str(budgets(args.budget_s)[1]))
+    t_start = time.monotonic()
+    if os.environ.get("CLOUDSC2_BENCH_HANG_RANK") == os.environ.get("RANK", "0"):  # tests/test_bench_launch.py: a rank that never answers
+        time.sleep(3600)
     if os.environ.get("CLOUDSC2_BENCH_FAIL_RANK") == os.environ.get("RANK", "0"):  # tests/test_bench_launch.py: a rank that dies at start
         print("bench.py: this rank was told to fail at start (CLOUDSC2_BENCH_FAIL_RANK)", file=sys.stderr)
         raise SystemExit(3)
@@ -349,9 +387,13 @@ def main():
         ad = c2dist.allreduce_max([5.0 + rank])
         per_rank = c2dist.allgather_scalar(float(col0))
         if rank == 0:
-            print(json.dumps({"metric": "rendezvous only (no GPU work)", "n_gpus": world, "rendezvous_only": True,
-                              "first_column_per_rank": per_rank, "columns_per_rank": ncols,
-                              "verdicts": {"tl_znormg": [float(x) for x in tl], "ad_znormg": float(ad[0])}}), flush=True)
+            line = {"metric": "rendezvous only (no GPU work)", "n_gpus": world, "rendezvous_only": True,
+                    "first_column_per_rank": per_rank, "columns_per_rank": ncols}
+            if world > 1:  # the same two-stage protocol as the measurement: the timing line first, the full line last
+                print(json.dumps({**line, "stage": "timing"}), flush=True)
+                line["stage"] = "final"
+            line["verdicts"] = {"tl_znormg": [float(x) for x in tl], "ad_znormg": float(ad[0])}
+            print(json.dumps(line), flush=True)
         if world > 1:
             torch.distributed.destroy_process_group()
         return
@@ -441,7 +483,6 @@ def main():
 
     k_avg = float(kms.mean())
     k_per_rank = c2dist.allgather_scalar(k_avg, dev) if world > 1 else [k_avg]
-    achieved = bpc * args.ngptot / (k_avg * 1e-3) / 1e9
     # HBM traffic: NOT measured in this run.  It is the figure of the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
     # separate runs, calibrated as the MI355X guide prescribes; tools/pmc_workload.py + tools/pmc_parse.py), scaled per column
     # to this launch; `traffic_source` names the file, null if there is none for this precision.
@@ -449,13 +490,23 @@ def main():
     if args.kernel == "ad":
         tkey = ("ad" if args.ad_sweep == "both" else "ad_reverse") + ("_assign" if args.ad_assign else "")
     traffic, tinfo = select_pmc_traffic(os.path.join(ROOT, "profiles"), tkey, args.ngptot, c2.binding.REAL_BYTES, bpc * args.ngptot)
+    # both byte conventions (BASELINE.md section 2 divides NL by the 27 440 B of the CLOUDSC2 dummies alone; the launch also writes
+    # the driver's CLD(:,:,NCLV)=0 plane: 28 536 B) and the counters' bytes over the same time
+    fr = roofline_fractions(k_avg, args.ngptot, bpc, c2.bytes_per_column(nlev, "nl") if args.kernel == "nl" else None, traffic)
+    achieved = fr["achieved"]
     roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "frac": fr["frac"], "traffic": traffic,
                 "traffic_over_algorithmic": (traffic / (bpc * args.ngptot)) if traffic else None, **tinfo, "bytes_per_column": bpc,
+                **{k: v for k, v in fr.items() if k not in ("achieved", "frac")},
                 "algorithmic_bytes": bpc * args.ngptot, "kernel_ms_avg": k_avg, "kernel_ms_min": float(kms.min()),
                 "kernel_ms_first_tenth": float(kms[:max(1, len(kms) // 10)].mean()), "kernel_ms_last_tenth": float(kms[-max(1, len(kms) // 10):].mean()),
                 "kernel_ms_avg_per_rank": [round(x, 5) for x in k_per_rank],
                 "allocation": "first and only state of the process, from cloudsc2_device_malloc_state (placed by the library)"}
+    if world > 1:  # every rank's placement next to its kernel time (a slow rank is a slow place or a slow GPU: this tells which)
+        pr = {k: c2dist.allgather_scalar(float(placement.get(k, 0.0)), dev) for k in ("candidates", "probe_ms_best", "probe_ms_median", "probe_ms_worst")}
+        roofline["placement_per_rank"] = [{"rank": r, "candidates": int(pr["candidates"][r]), "probe_ms_best": pr["probe_ms_best"][r],
+                                           "probe_ms_median": pr["probe_ms_median"][r], "probe_ms_worst": pr["probe_ms_worst"][r],
+                                           "kernel_ms_avg": round(k_per_rank[r], 5)} for r in range(world)]
     if args.kernel == "nl" and placement.get("candidates", 0) > 1 and not os.environ.get("CLOUDSC2_PLACE_PROBE"):
         # a state alone is judged by the NL sweep itself (zero-filled state in every candidate), so the allocator's probe times ARE
         # kernel times: what the median and the worst candidate of this box would have given
@@ -477,6 +528,12 @@ def main():
                    "placement": placement},
         "roofline": roofline,
     }
+    if world > 1 and rank == 0:
+        # The timing is complete here: it goes out NOW, as a line of its own with every field of the contract, before the verdict
+        # legs below touch RCCL again -- whatever happens there (a collective that never answers is ended by the watchdog with the
+        # process), the measurement is on record.  The full line, with `verdicts`, follows as the LAST line.
+        print(json.dumps({**out, "stage": "timing (the full line with the self-tests' verdicts follows; this one stands if it does not)",
+                          "seconds_since_start": round(time.monotonic() - t_start, 1)}), flush=True)
     companions = rank == 0 and world == 1 and args.kernel == "nl" and not args.no_companions
     if companions:
         # Everything below comes from fresh child processes started after this process has given its device memory back; none of
@@ -492,7 +549,9 @@ def main():
                 d = child_bench(["--kernel", kind, "--steps", 30, "--warmup", 5, "--ngptot", args.ngptot] + common)
                 comp[kind] = {"value": d["value"], "unit": d["unit"], "kernel_ms_avg": d["roofline"]["kernel_ms_avg"],
                               "bytes_per_column": d["roofline"]["bytes_per_column"], "frac": d["roofline"]["frac"],
-                              "traffic": d["roofline"]["traffic"], "kernel": d["roofline"]["kernel"],
+                              "traffic": d["roofline"]["traffic"], "traffic_over_algorithmic": d["roofline"]["traffic_over_algorithmic"],
+                              "frac_actual_bytes": d["roofline"]["frac_actual_bytes"], "traffic_source": d["roofline"].get("traffic_source"),
+                              "kernel": d["roofline"]["kernel"],
                               "placement": d["config"]["placement"]}
             except Exception as e:  # noqa: BLE001  (never let the companions break the headline line)
                 comp[kind] = {"error": repr(e)}
@@ -502,8 +561,11 @@ def main():
             d = child_bench(["--kernel", "nl", "--steps", 50, "--warmup", 5, "--ngptot", 1048576] + common)
             out["target_config"] = {"workload": d["config"]["workload"], "ngptot": 1048576, "steps": d["steps"], "value": d["value"],
                                     "unit": d["unit"], "ms_per_step": d["ms_per_step"], "kernel_ms_avg": d["roofline"]["kernel_ms_avg"],
-                                    "frac": d["roofline"]["frac"], "achieved": d["roofline"]["achieved"],
-                                    "bytes_per_column": d["roofline"]["bytes_per_column"], "placement": d["config"]["placement"],
+                                    "frac": d["roofline"]["frac"], "frac_kernel_only": d["roofline"].get("frac_kernel_only"),
+                                    "frac_actual_bytes": d["roofline"].get("frac_actual_bytes"), "achieved": d["roofline"]["achieved"],
+                                    "bytes_per_column": d["roofline"]["bytes_per_column"],
+                                    "bytes_per_column_kernel_only": d["roofline"].get("bytes_per_column_kernel_only"),
+                                    "placement": d["config"]["placement"],
                                     "target": "north_star: NL >= 0.70 of the 8 TB/s HBM3E peak at NGPTOT >= 1 M columns"}
         except Exception as e:  # noqa: BLE001
             out["target_config"] = {"error": repr(e)}
@@ -561,9 +623,10 @@ def main():
 
             th = threading.Thread(target=native_reductions, daemon=True)
             th.start()
-            th.join(120.0)
+            native_wait = budgets(args.budget_s)[1]
+            th.join(native_wait)
             if th.is_alive():
-                native = {"error": "no answer within 120 s"}
+                native = {"error": f"no answer within {native_wait:g} s"}
                 native_hung = True
             tl_ok, itest = c2.binding.taylor_verdict(ztl_g)
             out["verdicts"] = {"backend": torch.distributed.get_backend(),
@@ -573,6 +636,9 @@ def main():
         except Exception as e:  # noqa: BLE001
             out["verdicts"] = {"error": repr(e)}
     if rank == 0:
+        if world > 1:
+            out["stage"] = "final"
+            out["seconds_since_start"] = round(time.monotonic() - t_start, 1)
         print(json.dumps(out), flush=True)
     if native_hung:  # a thread of this rank still sits in the native communicator: leave without the orderly shutdown
         sys.stdout.flush()

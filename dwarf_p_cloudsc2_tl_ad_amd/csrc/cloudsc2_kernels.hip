@@ -266,7 +266,10 @@ template <class Args> using KernelFn = void (*)(Args);
       std::integer_sequence<unsigned, F...>) { return {{table##_entry<F>()...}}; }                                 \
   [[maybe_unused]] const std::array<KernelFn<Args>, NF> table = table##_make(std::make_integer_sequence<unsigned, NF>{});
 // (the trajectory pass differs from the plain NL sweep only with the evaporation branch: the cover checkpoint)
-C2_VARIANT_TABLE(g_nl_kernels, nl_kernel, NlArgs, 128, (F & C2F_CKPT) ? ((F & C2F_EVAP) && !(F & (C2F_PERT | C2F_NOLIN))) : true)
+// (the .NOT.LPHYLIN form exists for the plain sweep only: no shipped main uses it, the Taylor test's perturbed runs and the
+//  adjoint's trajectory pass belong to CLOUDSC2TL / CLOUDSC2AD, which have the LPHYLIN form alone)
+C2_VARIANT_TABLE(g_nl_kernels, nl_kernel, NlArgs, 128,
+                 (F & C2F_CKPT) ? ((F & C2F_EVAP) && !(F & (C2F_PERT | C2F_NOLIN))) : !((F & C2F_NOLIN) && (F & C2F_PERT)))
 C2_VARIANT_TABLE(g_tl_kernels, tl_kernel, TlArgs, 64, true)
 C2_VARIANT_TABLE(g_ad_reverse_kernels, ad_reverse_kernel, AdArgs, 64, !(F & C2F_ADNORM) || ((F & C2F_ASSIGN) && !(F & C2F_EVAP)))
 C2_VARIANT_TABLE(g_ad_kernels, ad_kernel, AdArgs, 64, C2_AD_FUSED != 0 && !(F & C2F_ADNORM))
@@ -367,9 +370,11 @@ validate_partial_kernel(const real_t* __restrict__ table, int klon, int period, 
   }
 }
 
-__global__ void validate_final_kernel(const double* __restrict__ part, int nparts, double* __restrict__ stats) {
+// fold_zero: the caller's blocking has padded columns the field's own blocking does not hold (caller NPROMA 100 pads 256 columns to
+// 300, the device's 2 x 128 blocks have none): they are zero in the caller's arrays and MINVAL / MAXVAL(FIELD(:,:,B)) include them
+__global__ void validate_final_kernel(const double* __restrict__ part, int nparts, double* __restrict__ stats, int fold_zero) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double vmin = INFINITY, vmax = -INFINITY, emax = 0.0, esum = 0.0, rsum = 0.0;
+  double vmin = fold_zero ? 0.0 : INFINITY, vmax = fold_zero ? 0.0 : -INFINITY, emax = 0.0, esum = 0.0, rsum = 0.0;
   for (int i = 0; i < nparts; ++i) {
     vmin = fmin(vmin, part[5 * i + 0]); vmax = fmax(vmax, part[5 * i + 1]); emax = fmax(emax, part[5 * i + 2]);
     esum += part[5 * i + 3]; rsum += part[5 * i + 4];
@@ -611,11 +616,17 @@ int nl_fair(long long ncols_pad, bool evap) {
   (void)evap;  // (the evaporation variants run two or three waves per SIMD as well)
   static const char* e = getenv("CLOUDSC2_FAIR");
   if (e && *e) return atoi(e) != 0;
-  static int simds = 0;
+  // SIMDs of the CURRENT device (a process may drive several GPUs, or change device between calls): cached per device id
+  constexpr int kMaxDev = 64;
+  static std::atomic<int> simds_of[kMaxDev];  // 0 = not asked yet (zero-initialised)
+  int dev = 0, simds = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = -1; }
+  if (dev >= 0 && dev < kMaxDev) simds = simds_of[dev].load(std::memory_order_relaxed);
   if (!simds) {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) simds = 4 * cus;
-    else simds = 1024;
+    int cus = 0;
+    if (dev >= 0 && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) simds = 4 * cus;
+    else { (void)hipGetLastError(); simds = 1024; }
+    if (dev >= 0 && dev < kMaxDev) simds_of[dev].store(simds, std::memory_order_relaxed);
   }
   const long long waves = (ncols_pad + 63) / 64, slots = 3LL * simds;
   return waves <= slots;
@@ -766,6 +777,8 @@ int cloudsc2_nl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
   if (precise_of(prm)) f |= C2F_PRECISE;
   if (args.c.evap) f |= C2F_EVAP;
   if (!prm->lphylin && !prm->ldrain1d) f |= C2F_NOLIN;  // cloudsc2.F90:349 (CLOUDSC2TL / CLOUDSC2AD have the LPHYLIN form only)
+  if ((f & C2F_NOLIN) && (f & C2F_PERT))
+    return fail(CLOUDSC2_EINVAL, "pert_lambda != 0 with LPHYLIN = 0: the perturbed runs of the Taylor test exist in the LPHYLIN form only");
   args.g.fair = nl_fair(g.ncols_pad, args.c.evap != 0);
   if (fits_off32(g, nproma, nlev, {s.full, s.half, s.cml, s.clv, s.loc, (long long)zero_plane.block_stride})) f |= C2F_OFF32;
   return launch_variant(g_nl_kernels[f], args, g.ncols_pad, (hipStream_t)stream);
@@ -973,7 +986,8 @@ static int validate_launch_impl(const cloudsc2_real* table, int klon, int period
   hipLaunchKernelGGL(validate_partial_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, table, klon, period, start,
                      nlevx, ndim, nproma, ngptot, nblocks, (const real_t*)field.ptr, field.block_stride, workspace,
                      ncols_minmax < 0 ? nblocks * nproma : ncols_minmax);
-  hipLaunchKernelGGL(validate_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double*)workspace, nparts, stats);
+  hipLaunchKernelGGL(validate_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double*)workspace, nparts, stats,
+                     (int)(ncols_minmax > nblocks * nproma));
   HIP_TRY(hipGetLastError());
   return 0;
 }

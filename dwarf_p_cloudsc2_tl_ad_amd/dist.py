@@ -40,7 +40,7 @@ def init_process_group(backend: str | None = None):
         # instead of torch's default half hour -- the launcher then sees a non-zero exit and stops the job
         import datetime
 
-        timeout = datetime.timedelta(seconds=float(os.environ.get("CLOUDSC2_DIST_TIMEOUT_S", "300")))
+        timeout = datetime.timedelta(seconds=float(os.environ.get("CLOUDSC2_DIST_TIMEOUT_S", "120")))
         dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
     return rank, local, world
 

@@ -389,12 +389,19 @@ class DeviceState:
         nbs = (self.ngptot + nps - 1) // nps
         n = C.c_longlong(0)
         B.check(B.lib.cloudsc2_taylor_sweep_work_doubles(self.nproma, self.ngptot, C.byref(n)))
-        work = self.torch.empty((n.value,), dtype=self.torch.float64, device=self.device)
+        # The sweep's workspace belongs to this state, one per stream it was ever launched on, and lives as long as the state: the
+        # launch is asynchronous on a stream torch's caching allocator may know nothing about (a raw hipStream_t), so a tensor
+        # dropped here could be handed out again while the sweep or the reduce kernel still reads it.
+        sh = self._stream(stream)
+        key = (int(sh.value or 0) if hasattr(sh, "value") else int(sh or 0), int(n.value))
+        cache = self.__dict__.setdefault("_taylor_work", {})
+        work = cache.get(key)
+        if work is None:
+            work = cache[key] = self.torch.empty((n.value,), dtype=self.torch.float64, device=self.device)
         sums = self.torch.zeros((10, nbs, 10, 2), dtype=self.torch.float64, device=self.device)
         i, o, t = self.traj_inputs(not fused_satur), self.traj_outputs(), tl_out.block()
         B.check(B.lib.cloudsc2_taylor_sweep_launch(C.byref(prm), self.ptsphy, self.nproma, self.nlev, self.ngptot, nps, C.byref(i), C.byref(o),
-                                                   C.byref(t), C.c_void_p(work.data_ptr()), C.c_void_p(sums.data_ptr()), self._stream(stream)))
-        self._keep = work  # until the stream has run the sweep
+                                                   C.byref(t), C.c_void_p(work.data_ptr()), C.c_void_p(sums.data_ptr()), sh))
         return sums
 
     def increments(self, zero_supsat: bool = False, into: FlatFields | None = None) -> FlatFields:

@@ -51,7 +51,10 @@ typedef struct cloudsc2_params {
   double rticecu, rtwat_rticecu_r;                                             /* YOETHF, dead branches only */
   int lphylin;   /* YREPHLI%LPHYLIN: 1 in every reference main (dwarf_cloudsc.F90:107).  0 selects the FOEALFA / FOEEWM form of the NL
                   * sweep's saturation pressure (cloudsc2.F90:349,365-369; unless ldrain1d); CLOUDSC2TL / CLOUDSC2AD and the driver's
-                  * SATUR call (cloudsc_driver_mod.F90:91: LDPHYLIN=.TRUE.) do not depend on it */
+                  * SATUR call (cloudsc_driver_mod.F90:91: LDPHYLIN=.TRUE.) do not depend on it: cloudsc2_tl_launch* and
+                  * cloudsc2_ad_launch* IGNORE this field and run the LPHYLIN form, as the reference's TL / AD do
+                  * (cloudsc2tl.F90 / cloudsc2ad.F90 have no other); cloudsc2_nl_launch with pert_lambda != 0 (a perturbed run of
+                  * the Taylor test) refuses lphylin = 0 with CLOUDSC2_EINVAL */
   int levapls2;  /* precipitation evaporation on/off (LEVAPLS2 .OR. LDRAIN1D, cloudsc2.F90:557) */
   int lregcl;    /* TL/AD regularisation (cloudsc2tl.F90:575,657,754,794,998) */
   int ldrain1d;
@@ -102,6 +105,14 @@ int cloudsc2_get_math_mode(void);
 #include <stddef.h>
 int cloudsc2_device_malloc(void** ptr, size_t bytes);
 void cloudsc2_device_malloc_info(int* candidates, double* best_ms, double* median_ms, double* worst_ms);
+/* Who is searched.  cloudsc2_device_malloc, cloudsc2_device_malloc_state and the resident states (cloudsc2_state_create and the
+ * scratch of their self-tests): yes.  The workspace of the HOST-ARRAY drivers cloudsc2_nl_run / cloudsc2_tl_taylor_run /
+ * cloudsc2_ad_symmetry_run: one plain hipMalloc -- those calls are PCIe-bound (55-71 ms per 160 000 columns against a 0.1 ms
+ * difference of the kernel), and a host model's free HBM is not taken transiently on their behalf; CLOUDSC2_PLACE=1 in the
+ * environment asks for the search there too.  Staging buffers of re-blocked transfers and the validator's workspace: never.
+ * CLOUDSC2_PLACE=0 switches every search off.  The counters say how many allocations of this process were searched (more than
+ * one candidate) and how many were plain. */
+void cloudsc2_device_malloc_counts(long long* searched, long long* plain);
 int cloudsc2_device_free(void* ptr);
 /* The same for a buffer that will hold a state of (nproma, nlev, ngptot) at its start (and whatever the caller keeps behind it:
  * perturbation sets, scratch): the placement search times the NL kernel itself on a zero-filled state laid out in every candidate

@@ -1,0 +1,59 @@
+"""bench.py itself on the GPU box: the one-GPU line's contract fields, and the N > 1 code path rehearsed with two ranks that share
+the one GPU (gloo for the collectives: RCCL refuses two ranks on one device) -- everything the first real 8-GPU run executes
+except RCCL itself: spawn, rendezvous, the timed region with its barriers, the MAX over ranks, the per-rank gathers, the timing
+line before the verdict legs, the Taylor / adjoint legs on each rank's sub-range, the reductions, the full line last."""
+from __future__ import annotations
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from tests.util import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _bench(args, env=None, timeout=600):
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *map(str, args)], capture_output=True, text=True,
+                          timeout=timeout, env=e, cwd=ROOT)
+
+
+def test_one_gpu_line_carries_both_byte_conventions():
+    r = _bench(["--steps", 20, "--warmup", 3, "--no-companions", "--no-cpu-baseline", "--ngptot", 65536])
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["unit"] == "columns/s" and d["dtype"] == "f64" and "stage" not in d
+    rf = d["roofline"]
+    assert rf["bytes_per_column"] == 28536 and rf["bytes_per_column_kernel_only"] == 27440
+    assert abs(rf["frac_kernel_only"] / rf["frac"] - 27440 / 28536) < 1e-12
+    assert abs(rf["frac"] - 28536 * 65536 / (rf["kernel_ms_avg"] * 1e-3) / 8e12) < 1e-9
+    assert 0.2 < rf["frac"] < 1.0 and d["ms_per_step"] >= rf["kernel_ms_avg"] * 0.999
+
+
+def test_two_ranks_on_one_gpu_rehearse_the_multi_gpu_path(tmp_path):
+    r = _bench(["--gpus", 2, "--steps", 10, "--warmup", 2, "--ngptot", 16384, "--budget-s", 300],
+               env={"CLOUDSC2_DIST_BACKEND": "gloo", "CLOUDSC2_BENCH_LOGDIR": str(tmp_path)})
+    assert r.returncode == 0, r.stderr[-3000:] + open(tmp_path / "bench_rank0.err").read()[-3000:]
+    relayed = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(relayed) == 1  # the parent relays ONE line: the last rank 0 printed
+    d = json.loads(relayed[0])
+    assert d["stage"] == "final" and d["n_gpus"] == 2 and d["scaling"] == "weak"
+    # rank 0's own stdout: the timing line first (complete contract, no verdicts), the full line last
+    own = [json.loads(ln) for ln in open(tmp_path / "bench_rank0.out").read().splitlines() if ln.startswith("{")]
+    assert len(own) == 2 and own[0]["stage"].startswith("timing") and "verdicts" not in own[0] and own[1] == d
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "dtype", "config", "roofline"):
+        assert own[0][k] == d[k], k
+    assert abs(d["value"] - 2 * 16384 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]  # whole job: both ranks' columns / max time
+    per = d["roofline"]["placement_per_rank"]
+    assert [p["rank"] for p in per] == [0, 1] and all(p["kernel_ms_avg"] > 0 for p in per)
+    assert per[0]["candidates"] == 1  # two ranks share the device: nothing is searched (cloudsc2_alloc.inc)
+    assert len(d["roofline"]["kernel_ms_avg_per_rank"]) == 2
+    v = d["verdicts"]
+    assert v["backend"] == "gloo" and v["tl_passed"] and v["ad_ok"] and len(v["tl_znormg"]) == 10, v

@@ -3,10 +3,13 @@ host restatements of EXPAND_R2/R3 (expand_mod.F90:270-335) and VALIDATE_R2/R3 (v
 file -> device state -> NL -> validation-report chain of the reference's main (dwarf_cloudsc.F90:79-124)."""
 from __future__ import annotations
 
+import json
+import os
+
 import numpy as np
 import pytest
 
-from tests.util import B, c2, refcall
+from tests.util import ROOT, B, c2, refcall
 from dwarf_p_cloudsc2_tl_ad_amd import fileio
 
 pytestmark = pytest.mark.gpu
@@ -303,7 +306,7 @@ def test_cpp_host_example_prints_the_same_report(tmp_path):
     assert r.stdout.rstrip("\n") == text
 
 
-@pytest.mark.parametrize("nproma,ngptot", [(96, 1000), (32, 1000), (100, 1000), (128, 1000), (1, 100), (1000, 2500)])
+@pytest.mark.parametrize("nproma,ngptot", [(96, 1000), (32, 1000), (100, 1000), (128, 1000), (1, 100), (1000, 2500), (100, 256)])
 def test_resident_state_handle_equals_the_host_pointer_drivers(nproma, ngptot):
     """cloudsc2_state_* (the library-owned resident GLOBAL_STATE the Fortran mains use with CLOUDSC2_RESIDENT=1): expand from
     the KLON-column tables, NL, download == the host-pointer driver on the host-tiled state, bit for bit; the two self-tests
@@ -332,6 +335,13 @@ def test_resident_state_handle_equals_the_host_pointer_drivers(nproma, ngptot):
         assert st[0] == min(act.min(), 0.0) and st[1] == max(act.max(), 0.0)
     else:
         assert st[0] == act.min() and st[1] == act.max()
+    # the same on an all-positive field (PT): the caller's padded tail is the only zero, and it counts even where the device's own
+    # blocking has no padding at all (caller NPROMA 100 pads 256 columns to 300, the device holds 2 x 128)
+    tcols = want.PT.transpose(0, 2, 1).reshape(-1, want.nlev)[:100]
+    stt = rs.validate(B.F_FULL["PT"], np.ascontiguousarray(tcols.T))
+    tact = want.PT.transpose(0, 2, 1).reshape(-1, want.nlev)[:ngptot]
+    assert stt[2] == 0.0 and tact.min() > 0.0
+    assert stt[0] == (0.0 if got.nblocks * nproma > ngptot else tact.min()) and stt[1] == tact.max()
 
     # the self-tests on the resident state vs. on host arrays
     prm_tl = c2.default_params(c2.ceta_from_table(tab), lregcl=False)
@@ -420,3 +430,41 @@ def test_device_allocator_places_and_frees():
         assert r.returncode == 0 and r.stdout.split()[:1] == ["OK"], r.stdout + r.stderr
         # (the second batch of candidates, taken when the first shows no class difference, shares the budget: at most `want`)
         assert 1 <= int(r.stdout.split()[1]) <= want, (env, r.stdout)
+
+
+def test_host_array_drivers_do_not_search_for_a_place():
+    """cloudsc2_nl_run / cloudsc2_tl_taylor_run / cloudsc2_ad_symmetry_run are PCIe-bound, so their workspace is
+    ONE plain hipMalloc (no candidates, no transient share of the host model's HBM) unless CLOUDSC2_PLACE=1 asks; the resident
+    state keeps the search.  Fresh processes (the allocator reads its switches once); 20 000 columns = 0.8 GB, above the 256 MiB
+    below which nothing is searched anyway."""
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, json; sys.path.insert(0, %r)\n"
+        "import dwarf_p_cloudsc2_tl_ad_amd as c2\n"
+        "from dwarf_p_cloudsc2_tl_ad_amd import binding as B\n"
+        "tab = c2.synthetic_table(); ceta = c2.ceta_from_table(tab); out = {}\n"
+        "st = c2.state_from_table(tab, 128, 20000)\n"
+        "c2.run_state(c2.default_params(ceta), st, 'nl'); out['nl'] = B.device_malloc_counts()\n"
+        "c2.run_state(c2.default_params(ceta, lregcl=False), c2.state_from_table(tab, 128, 20000), 'tl'); out['tl'] = B.device_malloc_counts()\n"
+        "c2.run_state(c2.default_params(ceta, lregcl=True), c2.state_from_table(tab, 128, 20000), 'ad'); out['ad'] = B.device_malloc_counts()\n"
+        "B.lib.cloudsc2_release_workspace()\n"
+        "rs = c2.ResidentState.from_table(tab, 128, 20000); out['resident'] = B.device_malloc_counts()\n"
+        "print(json.dumps(out))\n" % ROOT)
+
+    def run(env):
+        e = {k: v for k, v in os.environ.items() if not k.startswith("CLOUDSC2_PLACE")}
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env={**e, **env})
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]), r.stderr
+
+    d, err = run({"CLOUDSC2_PLACE_VERBOSE": "1"})
+    assert d["nl"][0] == 0 and d["nl"][1] >= 1, d           # one plain allocation, nothing searched
+    assert d["tl"][0] == 0 and d["ad"][0] == 0, d           # (the TL / AD workspaces are larger: re-allocated, still plain)
+    assert d["resident"][0] == 1, d                          # cloudsc2_state_create: searched
+    assert "host-array driver workspace: searched only with CLOUDSC2_PLACE=1" in err
+    d1, _ = run({"CLOUDSC2_PLACE": "1"})
+    assert d1["nl"][0] == 1, d1                              # asked for explicitly: searched
+    d0, _ = run({"CLOUDSC2_PLACE": "0"})
+    assert d0["resident"][0] == 0 and d0["nl"][0] == 0, d0  # every search off

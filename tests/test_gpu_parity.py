@@ -385,6 +385,8 @@ def test_full_size_tl_ad_properties():
         assert torch.equal(dy2.t[n], 2.0 * dy.t[n]), n
     # adjoint identity per column; the AD consumes (zeroes) its output adjoints and accumulates into zeroed input adjoints
     norm1 = sum((columns(t) ** 2).sum(dim=1) for t in dy.t.values())
+    sample = (0, 1, 625, ds.nb - 1)  # blocks compared DIRECTLY with the checker below (block 0 alone holds all 100 distinct columns)
+    tl_dev = {ibl: {n: t[ibl].cpu().numpy() for n, t in dy.t.items()} for ibl in sample}
     xa = c2.FlatFields("in", ds.nb, ds.nlev, ds.nproma, ds.device)
     scratch = ds.new_scratch()
     ds.ad(prm, xa, dy, scratch)
@@ -399,8 +401,31 @@ def test_full_size_tl_ad_properties():
         c = columns(t)
         assert torch.equal(c.reshape(-1, 100, c.shape[1]), c[:100].expand(ngptot // 100, 100, c.shape[1])), n
 
+    # The same 160 000-column launches against CLOUDSC2TL / CLOUDSC2AD themselves (cloudsc2tl.F90:10-24, cloudsc2ad.F90:10-24),
+    # block by block for a sample of blocks: every TL output and every input adjoint of every column of those blocks.  Together
+    # with the bit-periodicity asserted above (column g == column g mod 100 for ALL 160 000 columns of every TL output and every
+    # input adjoint, and block 0 holds columns 0..99) this is the oracle comparison of the metric's exact size, not a property.
+    chk = checker()
+    set_lib_params(chk, prm)
+    worst_tl = worst_ad = 0.0
+    for ibl in sample:
+        stb = c2.state_from_table(tab, nproma, nproma, col0=ibl * nproma)  # the host copy of this block's inputs
+        qs = ref_qsat(chk, stb)[0]
+        dinp = {n: np.ascontiguousarray(t[ibl].cpu().numpy()) for n, t in dx.t.items()}
+        o5, do = chk.cloudsc2tl(stb.ptsphy, refcall.block_inputs(stb, 0, qs), dinp, kfdia=nproma, ldrain1d=False)
+        for n in do:
+            worst_tl = max(worst_tl, relerr(do[n], tl_dev[ibl][n]))
+        ain = {n: np.zeros_like(a) for n, a in dinp.items()}
+        aout = {n: a.copy() for n, a in do.items()}
+        chk.cloudsc2ad(stb.ptsphy, refcall.block_inputs(stb, 0, qs), ain, aout, kfdia=nproma, ldrain1d=False)
+        for n in ain:
+            got = xa.t[n][ibl].cpu().numpy()
+            worst_ad = max(worst_ad, np.abs(got - ain[n]).max() / max(np.abs(ain[n]).max(), 1e-300))
+    print(f"160 000 columns, blocks {sample} against CLOUDSC2TL / CLOUDSC2AD: worst TL {worst_tl:.1e}, worst AD {worst_ad:.1e}")
+    assert worst_tl <= TLAD_TOL and worst_ad <= TLAD_TOL, (worst_tl, worst_ad)
 
-@pytest.mark.parametrize("nproma", [32, 128])
+
+@pytest.mark.parametrize("nproma", [32, 64, 128, 256])
 def test_full_size_nl_matches_the_reference_directly(nproma):
     """BASELINE configs[1] at its full size, compared DIRECTLY (every output, every column) with the checker's own driver:
     160 000 columns x 137 levels, state tiled on the device (cloudsc2_expand_launch) vs. the same state tiled on the host

@@ -20,6 +20,13 @@ if os.path.exists(os.path.join(src, "bench_prof_1m.json")):  # the north_star ta
     cp("bench_prof_1m.json", "bench_1m_under_rocprof.json")
     cp("bench_prof_1m_timed_region.json", "bench_1m_under_rocprof_timed_region.json")
     shutil.copy(glob.glob(os.path.join(src, "prof_1m", "*", "*kernel_stats.csv"))[0], os.path.join(dst, f"{prefix}_bench_1m_kernel_stats.csv"))
+if os.path.exists(os.path.join(src, "timed_kernel_stats.csv")):  # one row per timed kernel (NL, TL, AD, AD reverse, Taylor) and size
+    cp("timed_kernel_stats.csv", "timed_kernel_stats.csv")
+    for d in sorted(glob.glob(os.path.join(src, "prof_*_*"))):  # rocprofv3's own --stats summaries of those runs
+        for f in glob.glob(os.path.join(d, "*", "*kernel_stats.csv")):
+            shutil.copy(f, os.path.join(dst, f"{prefix}_{os.path.basename(d)[5:]}_kernel_stats.csv"))
+    for f in glob.glob(os.path.join(src, "bench_prof_*_*.json")):
+        shutil.copy(f, os.path.join(dst, f"{prefix}_{os.path.basename(f)[6:-5]}_under_rocprof.json"))
 if os.path.exists(os.path.join(src, "pytest_gpu.log")):
     cp("pytest_gpu.log", "pytest_gpu.log")
 for opt in ("rocm_smi_during_bench.txt", "single_checks_gpu.log"):

@@ -18,6 +18,22 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/p
 python tools/trace_timed_region.py $out/prof/*/*_kernel_trace.csv nl_kernel 1000 > $out/bench_prof_timed_region.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_1m -- python3 bench.py --ngptot 1048576 --steps 50 --no-cpu-baseline --no-companions > $out/bench_prof_1m.json 2> $out/bench_prof_1m.err || exit 1
 python tools/trace_timed_region.py $out/prof_1m/*/*_kernel_trace.csv nl_kernel 50 > $out/bench_prof_1m_timed_region.json
+# rocprofv3 kernel-trace of EVERY timed kernel, not NL alone: the same bench command per kernel, the program
+# directly after `--`, no child processes; the last K dispatches are the timed region (tools/kernel_stats_rows.py)
+specs=""
+for n in 160000 1048576; do
+  for kf in "tl:--kernel tl:tl_kernel:57072" "ad:--kernel ad:ad_kernel:85608" "adrev:--kernel ad --ad-sweep reverse --ad-assign:ad_reverse_kernel:59264"; do
+    lab=${kf%%:*}; rest=${kf#*:}; flags=${rest%%:*}; rest=${rest#*:}; pat=${rest%%:*}; bpc=${rest#*:}
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_${lab}_$n -- python3 bench.py $flags --ngptot $n --steps 30 --warmup 3 --no-cpu-baseline --no-companions > $out/bench_prof_${lab}_$n.json 2> $out/bench_prof_${lab}_$n.err || exit 1
+    specs="$specs ${lab}_$n:$(ls $out/prof_${lab}_$n/*/*_kernel_trace.csv):$pat:30:$n:$bpc"
+  done
+  # the two self-tests as whole driver calls on a resident state: taylor_kernel (the lambda sweep), tl_kernel with C2F_TRAJ|C2F_SELFINC,
+  # ad_reverse_kernel with C2F_ADNORM; each test runs 4 times, the last 3 are reported
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_selftests_$n -- python3 bench.py --self-tests --ngptot $n > $out/bench_prof_selftests_$n.json 2> $out/bench_prof_selftests_$n.err || exit 1
+  specs="$specs taylor_$n:$(ls $out/prof_selftests_$n/*/*_kernel_trace.csv):taylor_kernel:3:$n:0"
+done
+specs="nl_160000:$(ls $out/prof/*/*_kernel_trace.csv):nl_kernel:1000:160000:28536 nl_1048576:$(ls $out/prof_1m/*/*_kernel_trace.csv):nl_kernel:50:1048576:28536 $specs"
+python tools/kernel_stats_rows.py $out/timed_kernel_stats.csv $specs
 for n in 160000 1048576; do
   CLOUDSC2_PLACE=0 PMC_NGPTOT=$n timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_$n -- python3 tools/pmc_workload.py > $out/pmc_fetch_$n.log 2>&1 || exit 1
   CLOUDSC2_PLACE=0 PMC_NGPTOT=$n timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write_$n -- python3 tools/pmc_workload.py > $out/pmc_write_$n.log 2>&1 || exit 1
