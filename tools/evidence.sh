@@ -1,10 +1,13 @@
 #!/bin/bash
 # One GPU session that regenerates the judged evidence: tests, smoke, default bench line, rocprofv3 kernel stats of the same bench
 # command at 160 000 and at 1 048 576 columns, PMC traffic passes (separate --pmc runs), TL/AD and 1M-column bench lines.
-# usage: tools/evidence.sh TAG    (outputs under gpurun_out/TAG/; tools/collect_profiles.py copies the summaries to profiles/)
-tag=${1:-ev}; out=gpurun_out/$tag; mkdir -p $out
+# usage: tools/evidence.sh TAG [a|b|all]   (outputs under gpurun_out/TAG/; tools/collect_profiles.py copies the summaries to profiles/)
+# stage a: tests, smoke, the default line, rocprofv3 kernel-trace of every timed kernel; stage b: the PMC passes and the other bench
+# lines (one gpurun call holds at most 20 minutes: a and b are two calls)
+tag=${1:-ev}; stage=${2:-all}; out=gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
-timeout -k 10 600 python -m pytest tests -m gpu -q > $out/pytest_gpu.log 2>&1; tail -2 $out/pytest_gpu.log
+if [ "$stage" != b ]; then
+timeout -k 10 900 python -m pytest tests -m gpu -q > $out/pytest_gpu.log 2>&1; tail -2 $out/pytest_gpu.log
 timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1 && echo smoke ok || { echo smoke FAILED; tail -5 $out/smoke.log; }
 # what the box is and how it clocks while the kernel runs (boxes of the pool measure up to 12 % apart)
 rocm-smi --showproductname --showclocks --showpower --showperflevel --showmemvendor > $out/rocm_smi_idle.txt 2>&1
@@ -34,6 +37,8 @@ for n in 160000 1048576; do
 done
 specs="nl_160000:$(ls $out/prof/*/*_kernel_trace.csv):nl_kernel:1000:160000:28536 nl_1048576:$(ls $out/prof_1m/*/*_kernel_trace.csv):nl_kernel:50:1048576:28536 $specs"
 python tools/kernel_stats_rows.py $out/timed_kernel_stats.csv $specs
+fi
+[ "$stage" = a ] && exit 0
 for n in 160000 1048576; do
   CLOUDSC2_PLACE=0 PMC_NGPTOT=$n timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_$n -- python3 tools/pmc_workload.py > $out/pmc_fetch_$n.log 2>&1 || exit 1
   CLOUDSC2_PLACE=0 PMC_NGPTOT=$n timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write_$n -- python3 tools/pmc_workload.py > $out/pmc_write_$n.log 2>&1 || exit 1
