@@ -749,6 +749,141 @@ C2_HD void tl_column(long long gcol, TlArgsP a) {
   }
 }
 
+// -DC2_TL_DMA=1 (experiment, profiles/EXPERIMENTS.md section 6; default off; NPROMA 128 only): the TL sweep with its look-ahead in
+// LDS instead of registers.  A 128-thread workgroup is one NPROMA block row, so a level's row of any plane is 1 KiB contiguous: ONE
+// 16-byte-per-lane LDS-DMA load (global_load_lds_dwordx4, no VGPR destination) by one wave fetches it for both waves.  Wave 0 requests
+// the 16 trajectory rows of level jk+1, wave 1 the 16 perturbation rows, at the top of level jk; after the level's stores both waves
+// meet, read their columns' 32 values (ds_read_b64) and meet again before the buffer is overwritten.  32 KiB per workgroup (four
+// workgroups = 2 waves per SIMD fit a CU's 160 KiB), no second register set: the kernel is meant to be built with -DC2_TL_WAVES=2.
+#ifndef C2_TL_DMA
+#define C2_TL_DMA 0
+#endif
+#if C2_TL_DMA && defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void global_cvoid_t;
+// one 1 KiB row: lane l of the calling wave moves 16 bytes from src (+ 16 l, already in `src`) to row[16 l]
+__device__ __forceinline__ void dma_row(const real_t* plane, long long elem_off, real_t* row) {
+  __builtin_amdgcn_global_load_lds((global_cvoid_t*)(plane + elem_off), (lds_void_t*)row, 16, 0, 2 /* nt */);
+}
+// the 16 rows of one input set for level jk (RawLevel order), `o`: offsets of column (block start + 2 * lane) in each layout group
+template <bool HAS_QSAT>
+__device__ __forceinline__ void dma_level(InPtrsP pp, const LaneOff& o, int nproma, int nlev, int jk, real_t (*rows)[128], int first, int count) {
+  const InPtrs p = *pp;
+  const long long d = (long long)jk * nproma, d1 = d + nproma;
+  const real_t* src[16] = {p.paph, p.pap, p.q, p.qsat, p.t, p.l, p.i, p.lude, p.lu, p.mfu, p.mfd, p.gt, p.gq, p.gl, p.gi, p.supsat};
+  const long long off[16] = {o.half + d1, o.full + d, o.full + d, o.full + d, o.full + d, o.clv + d, o.clv + d, o.full + d, o.full + d1,
+                             o.full + d, o.full + d, o.cml + d, o.cml + d, o.cml + d, o.cml + d, o.full + d};
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    if (k < first || k >= first + count) continue;
+    if (k == 3 && !HAS_QSAT) continue;
+    if (k == 8 && jk + 1 >= nlev) continue;  // PLU(JK+1) below the last level: 0 (load_level)
+    dma_row(src[k], off[k], rows[k]);
+  }
+}
+template <bool HAS_QSAT>
+__device__ __forceinline__ void rows_get(real_t (*rows)[128], int nlev, int jk, RawLevel& r) {
+  const int t = threadIdx.x;
+  r.paph_k1 = rows[0][t]; r.pap = rows[1][t]; r.q = rows[2][t]; if (HAS_QSAT) r.qsat = rows[3][t]; r.t = rows[4][t]; r.l = rows[5][t];
+  r.i = rows[6][t]; r.lude = rows[7][t]; r.lu_k1 = (jk + 1 < nlev) ? rows[8][t] : RC(0.0); r.mfu = rows[9][t]; r.mfd = rows[10][t];
+  r.gt = rows[11][t]; r.gq = rows[12][t]; r.gl = rows[13][t]; r.gi = rows[14][t]; r.supsat = rows[15][t];
+}
+
+template <unsigned F>
+__device__ __forceinline__ void tl_column_dma(TlArgsP a) {
+  constexpr bool HAS_QSAT = (F & C2F_QSAT) != 0, P = (F & C2F_PRECISE) != 0, STORE_TRAJ = (F & C2F_TRAJ) != 0, EVAP = (F & C2F_EVAP) != 0;
+  constexpr bool SELFINC = (F & C2F_SELFINC) != 0;
+  typedef typename std::conditional<(F & C2F_OFF32) != 0, unsigned, long long>::type OT;
+  __shared__ real_t rows_t[16][128], rows_p[16][128];
+  const long long gcol = (long long)blockIdx.x * 128 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  LaneOff o, op, orow, oprow; bool active, dummy;
+  if (!lane_setup(&a->g, &a->s, gcol, o, active)) return;  // (whole workgroups only: ncols_pad is a multiple of NPROMA = 128)
+  lane_setup(&a->g, &a->sp, gcol, op, active);
+  lane_setup(&a->g, &a->s, (long long)blockIdx.x * 128 + 2 * lane, orow, dummy);   // the 16 bytes this lane moves of every row
+  lane_setup(&a->g, &a->sp, (long long)blockIdx.x * 128 + 2 * lane, oprow, dummy);
+  const int nlev = a->g.nlev, nproma = a->g.nproma;
+  LevelTabP tab = (LevelTabP)a->tab;
+  ConstsP c = C2_CONSTS(a);
+  InPtrsP in = &a->in, din = &a->din;
+  OutPtrsP out = &a->out, dout = &a->dout;
+
+  real_t ztrpaus = tropopause<false>(c, tab, in, o, &a->g, RC(0.0));
+  RhCrit rh;
+  rhcrit_setup(ztrpaus, rh);
+  real_t paph_surf = RC(0.0), dpaph_surf = RC(0.0);
+  if (EVAP) {
+    paph_surf = in->paph[o.half + (long long)nlev * nproma];
+    dpaph_surf = SELFINC ? paph_surf * RC(0.01) : din->paph[op.half + (long long)nlev * nproma];
+  }
+  if (active) {
+    if (STORE_TRAJ) store_top(out, o, c);
+    store_top(dout, op, c);
+  }
+  Carry cy; cy.rfl = RC(0.0); cy.sfl = RC(0.0); cy.covptot = RC(0.0);
+  Carry dcy; dcy.rfl = RC(0.0); dcy.sfl = RC(0.0); dcy.covptot = RC(0.0);
+  RawLevel cur, dcur;
+  double yy = 0.0;
+  real_t paph_k = in->paph[o.half], dpaph_k = SELFINC ? paph_k * RC(0.01) : din->paph[op.half];
+  const LaneOffT<OT> ol = lane_off_as<OT>(o), opl = lane_off_as<OT>(op);
+
+  // who requests what: with a perturbation set wave 0 takes the trajectory rows and wave 1 the perturbation rows; without
+  // (SELFINC: the increments are formed from the trajectory) the two waves take eight trajectory rows each
+  auto request = [&](int jk) {
+    if (SELFINC) dma_level<HAS_QSAT>(in, orow, nproma, nlev, jk, rows_t, wave * 8, 8);
+    else if (wave == 0) dma_level<HAS_QSAT>(in, orow, nproma, nlev, jk, rows_t, 0, 16);
+    else dma_level<true>(din, oprow, nproma, nlev, jk, rows_p, 0, 16);
+  };
+  request(0);
+  __syncthreads();
+  rows_get<HAS_QSAT>(rows_t, nlev, 0, cur);
+  if (!SELFINC) rows_get<true>(rows_p, nlev, 0, dcur);
+  __syncthreads();
+
+  for (int jk = 0; jk < nlev; ++jk) {
+    const bool last = (jk == nlev - 1);
+    TlArgsP ap = a;
+    C2_LAUNDER(ap);
+    in = &ap->in; din = &ap->din;
+    if (!last) request(jk + 1);
+    if (!HAS_QSAT) cur.qsat = satur_point<P>(c, cur.pap, cur.t);
+    if (SELFINC) self_increment(cur, ap->supsat_inc, dcur);
+
+    LevelCst k;
+    level_cst(tab, jk, last, k);
+    LevelIn x, dx;
+    make_level_in(cur, paph_k, paph_surf, x);
+    make_level_in(dcur, dpaph_k, dpaph_surf, dx);
+    LevelTraj tr;
+    LevelOut lo, dlo;
+    level_forward<P, EVAP>(c, k, rh, x, cy, tr, lo);
+    level_tl(c, k, x, tr, dx, dcy, dlo);
+    C2_LAUNDER(ap);
+    out = &ap->out; dout = &ap->dout;
+    if (active) {
+      if (STORE_TRAJ) store_out(out, ol, nproma, jk, lo);
+      store_out(dout, opl, nproma, jk, dlo);
+    }
+    if (SELFINC) {
+      yy += (double)dlo.tent * dlo.tent + (double)dlo.tenq * dlo.tenq + (double)dlo.tenl * dlo.tenl + (double)dlo.teni * dlo.teni +
+            (double)dlo.clc * dlo.clc + (double)dlo.covptot * dlo.covptot + (double)dlo.fplsl * dlo.fplsl + (double)dlo.fplsn * dlo.fplsn +
+            (double)dlo.fhpsl * dlo.fhpsl + (double)dlo.fhpsn * dlo.fhpsn;
+    }
+    paph_k = cur.paph_k1; dpaph_k = dcur.paph_k1;
+    if (!last) {
+      __syncthreads();  // (waits for this wave's own requests, then for the other wave's)
+      rows_get<HAS_QSAT>(rows_t, nlev, jk + 1, cur);
+      if (!SELFINC) rows_get<true>(rows_p, nlev, jk + 1, dcur);
+      __syncthreads();  // everybody has read: the rows may be overwritten
+    }
+  }
+  if (SELFINC && active) {
+    double* p = a->yy;
+    if (p) p[gcol] = yy;
+  }
+}
+#endif
+
 // ---------------------------------------------------------------------------------------------------------
 // AD for one column.  Two passes: the trajectory pass is nl_column<.., CKPT=true> -- it writes the trajectory
 // outputs and checkpoints the carries (rain and snow flux live in the outputs PFPLSL5/PFPLSN5 that have to be

@@ -27,7 +27,13 @@
 #include <vector>
 
 #include "../../include/cloudsc2_hip.h"
-#include "cloudsc2_column.hpp"
+#include "cloudsc2_sweep_kernels.hpp"
+#ifdef C2_SINGLE_TU  // one translation unit (experiment / diagnostic builds): the family units are part of this one
+#include "cloudsc2_kern_nl.hip"
+#include "cloudsc2_kern_tl.hip"
+#include "cloudsc2_kern_ad.hip"
+#include "cloudsc2_kern_taylor.hip"
+#endif
 
 using namespace cloudsc2;
 
@@ -132,148 +138,13 @@ int get_tables(const cloudsc2_params& p, const LevelTab** dev, int* kb0, int* kb
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// kernels: thin wrappers around the per-column functions of cloudsc2_column.hpp.  Every kernel has ONE by-value
-// argument block; the device code reads it in place from the kernel-argument segment (scalar cache).
+// kernels: the sweeps' __global__ wrappers and their variant tables are cloudsc2_sweep_kernels.hpp + the family units
+// cloudsc2_kern_{nl,tl,ad,taylor}.hip; here: SATUR as a kernel of its own, the data-format kernels and the test-norm kernels
 // ---------------------------------------------------------------------------------------------------------
-#ifndef C2_BLOCK
-#define C2_BLOCK 128
-#endif
-constexpr int kBlock = C2_BLOCK;
-// minimum waves per SIMD requested from the register allocator (0 = let the compiler decide)
-#ifndef C2_NL_WAVES
-#define C2_NL_WAVES 0
-#endif
-#ifndef C2_TL_WAVES
-#define C2_TL_WAVES 0
-#endif
-#ifndef C2_AD_WAVES
-#define C2_AD_WAVES 0
-#endif
-#define C2_BOUNDS(w) __launch_bounds__(kBlock, (w) > 0 ? (w) : 1)
-
-__device__ __forceinline__ long long global_column() { return (long long)blockIdx.x * blockDim.x + threadIdx.x; }
-
-#if defined(__HIP_DEVICE_COMPILE__)
-template <class T>
-__device__ __forceinline__ const C2_CONST_AS T* kernarg() {
-  return (const C2_CONST_AS T*)__builtin_amdgcn_kernarg_segment_ptr();
-}
-#define C2_KERNEL_BODY(call) call
-#else
-#define C2_KERNEL_BODY(call)
-#endif
-
 template <bool P>
 __global__ void __launch_bounds__(kBlock) satur_kernel(SaturArgs args) {
   C2_KERNEL_BODY(satur_column<P>(global_column(), kernarg<SaturArgs>()));
 }
-
-// The NL variants without the evaporation branch fit 168 VGPRs (3 waves per SIMD) even with the two-level-deep
-// prefetch; asking for it keeps the allocator from spending a few registers too many.  The others take what they need.
-// -DC2_WAVE_TIMES (diagnostic build, tools/wave_times.py): every wave of the NL kernel logs when it started and ended (the 100 MHz
-// constant clock) and where it ran (HW_ID, XCC_ID) -- how evenly a launch's waves start, progress and finish.
-#ifdef C2_WAVE_TIMES
-__device__ unsigned long long* g_wave_log = nullptr;  // [wave][4]: start, end, HW_ID, XCC_ID
-#define C2_WAVE_LOG_BEGIN const unsigned long long c2_t0 = __builtin_amdgcn_s_memrealtime();
-#define C2_WAVE_LOG_END                                                                                         \
-  if (g_wave_log && (threadIdx.x & 63) == 0) {                                                                  \
-    unsigned long long* e = g_wave_log + 4 * (((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);         \
-    e[0] = c2_t0; e[1] = __builtin_amdgcn_s_memrealtime();                                                     \
-    e[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4); e[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);        \
-  }
-#else
-#define C2_WAVE_LOG_BEGIN
-#define C2_WAVE_LOG_END
-#endif
-template <unsigned F>
-__global__ void __launch_bounds__(kBlock, (C2_NL_WAVES > 0) ? C2_NL_WAVES : ((F & C2F_EVAP) ? 1 : 3)) nl_kernel(NlArgs args) {
-  C2_KERNEL_BODY(C2_WAVE_LOG_BEGIN);
-  C2_KERNEL_BODY((nl_column<F>(global_column(), kernarg<NlArgs>())));
-  C2_KERNEL_BODY(C2_WAVE_LOG_END);
-}
-
-// fp32 only: the TL variants with 32-bit offsets and without the evaporation branch need 173 VGPRs; held to 168 (3 waves
-// per SIMD) they spill at most 7 dwords, and all 2500 waves of a 160 000-column launch are resident at once instead of
-// 2048 + 452 (0.94 -> 0.88 ms).  Every other TL variant, and the fp64 ones, spill heavily below what they ask for.
-template <unsigned F>
-__global__ void __launch_bounds__(kBlock, (C2_TL_WAVES > 0) ? C2_TL_WAVES
-                                          : (sizeof(real_t) == 4 && (F & C2F_OFF32) && !(F & C2F_EVAP)) ? 3 : 1)
-tl_kernel(TlArgs args) {
-  C2_KERNEL_BODY(C2_WAVE_LOG_BEGIN);
-  C2_KERNEL_BODY((tl_column<F>(global_column(), kernarg<TlArgs>())));
-  C2_KERNEL_BODY(C2_WAVE_LOG_END);
-}
-
-// C2_AD_FUSED=1: one kernel runs a column's trajectory pass and then its reverse pass (waves in the bandwidth-heavy
-// forward phase and waves in the arithmetic-heavy reverse phase share the CUs); 0: two kernels in stream order;
-// 2: both are built and launches of at most kAdSplitBelow columns take the two-kernel form.  fp64: the two forms measure
-// the same at every size (both passes need one wave per SIMD's worth of registers in the fused kernel anyway).  fp32: the
-// trajectory pass alone runs six waves per SIMD instead of the fused kernel's two, which is worth 7 % when the whole
-// launch is one round of waves (160 000 columns: 1.71 -> 1.59 ms) and nothing at 1 M columns (9.09 vs 9.17 ms).
-#ifndef C2_AD_FUSED
-#if defined(CLOUDSC2_SINGLE)
-#define C2_AD_FUSED 2
-#else
-#define C2_AD_FUSED 1
-#endif
-#endif
-constexpr long long kAdSplitBelow = 400000;
-__device__ __forceinline__ double wave_max(double v);
-__device__ __forceinline__ void atomic_max_pos(double* addr, double v);
-template <unsigned F>
-__global__ void C2_BOUNDS(C2_AD_WAVES) ad_reverse_kernel(AdArgs args) {
-  C2_KERNEL_BODY(C2_WAVE_LOG_BEGIN);
-#if defined(__HIP_DEVICE_COMPILE__)
-  if constexpr ((F & C2F_ADNORM) != 0) {  // the adjoint test's norms formed in the sweep: the wave's largest |norm3| joins the global one
-    const double m = wave_max(ad_reverse_column<F>(global_column(), kernarg<AdArgs>()));
-    if ((threadIdx.x & 63) == 0) atomic_max_pos(kernarg<AdArgs>()->gmax, m);
-  } else {
-    ad_reverse_column<F>(global_column(), kernarg<AdArgs>());
-  }
-#endif
-  C2_KERNEL_BODY(C2_WAVE_LOG_END);
-}
-template <unsigned F>
-__global__ void C2_BOUNDS(C2_AD_WAVES) ad_kernel(AdArgs args) {
-  C2_KERNEL_BODY(C2_WAVE_LOG_BEGIN);
-  C2_KERNEL_BODY((nl_column<(F & ~C2F_ASSIGN) | C2F_CKPT>(global_column(), &kernarg<AdArgs>()->nl)));
-  C2_KERNEL_BODY((ad_reverse_column<F>(global_column(), kernarg<AdArgs>())));
-  C2_KERNEL_BODY(C2_WAVE_LOG_END);
-}
-
-// The ten perturbed NL runs of the Taylor test in one sweep, the lambdas on the lanes (taylor_column): the grid is over THREADS,
-// 64 per kTaylorCols columns.  A wave reads 6 columns = 48 bytes of every 128-byte line it touches, so two or three consecutive
-// waves share each line -- the one sweep whose workgroups share data.  Blocks are dealt round-robin over the 8 XCDs (b and b + 8
-// share one, each XCD with its own L2): consecutive LOGICAL blocks are therefore mapped to physical blocks 8 apart, so that the
-// waves sharing a line sit on one XCD and its L2 fetches the line once (the grid is a multiple of 8 blocks; logical blocks past the
-// end find no column and leave).  Measured (rocprofv3 --pmc FETCH_SIZE, 160 000 columns): see profiles/r03_taylor_sweep_ab.txt.
-template <unsigned F>
-__global__ void __launch_bounds__(kBlock) taylor_kernel(TaylorArgs args) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  const unsigned per_xcd = gridDim.x >> 3;
-  const long long block = (long long)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-  taylor_column<F>(block * blockDim.x + threadIdx.x, kernarg<TaylorArgs>());
-#endif
-}
-
-// Variant tables: kernel<F> for every valid flag combination F, indexed by F (see C2F_* in cloudsc2_column.hpp).
-template <class Args> using KernelFn = void (*)(Args);
-#define C2_VARIANT_TABLE(table, kern, Args, NF, valid_expr)                                                        \
-  template <unsigned F> constexpr KernelFn<Args> table##_entry() {                                                 \
-    if constexpr (valid_expr) return kern<F>; else return nullptr;                                                 \
-  }                                                                                                                \
-  template <unsigned... F> constexpr std::array<KernelFn<Args>, sizeof...(F)> table##_make(                        \
-      std::integer_sequence<unsigned, F...>) { return {{table##_entry<F>()...}}; }                                 \
-  [[maybe_unused]] const std::array<KernelFn<Args>, NF> table = table##_make(std::make_integer_sequence<unsigned, NF>{});
-// (the trajectory pass differs from the plain NL sweep only with the evaporation branch: the cover checkpoint)
-// (the .NOT.LPHYLIN form exists for the plain sweep only: no shipped main uses it, the Taylor test's perturbed runs and the
-//  adjoint's trajectory pass belong to CLOUDSC2TL / CLOUDSC2AD, which have the LPHYLIN form alone)
-C2_VARIANT_TABLE(g_nl_kernels, nl_kernel, NlArgs, 128,
-                 (F & C2F_CKPT) ? ((F & C2F_EVAP) && !(F & (C2F_PERT | C2F_NOLIN))) : !((F & C2F_NOLIN) && (F & C2F_PERT)))
-C2_VARIANT_TABLE(g_tl_kernels, tl_kernel, TlArgs, 64, true)
-C2_VARIANT_TABLE(g_ad_reverse_kernels, ad_reverse_kernel, AdArgs, 64, !(F & C2F_ADNORM) || ((F & C2F_ASSIGN) && !(F & C2F_EVAP)))
-C2_VARIANT_TABLE(g_ad_kernels, ad_kernel, AdArgs, 64, C2_AD_FUSED != 0 && !(F & C2F_ADNORM))
-C2_VARIANT_TABLE(g_taylor_kernels, taylor_kernel, TaylorArgs, 64, !(F & (C2F_PERT | C2F_CKPT)))
 
 // ---------------------------------------------------------------------------------------------------------
 // Data-format kernels either side of the path: the input file holds KLON (=100) columns,
@@ -400,11 +271,6 @@ __device__ __forceinline__ double wave_sum(double v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
   return v;
 }
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
-  return v;
-}
 
 // ERROR_NORM sums (cloudsc_driver_tl_mod.F90:21-31): one thread block per NPROMA block, lanes stride the
 // block's active columns, per-lane level sums, wave shuffles, then one LDS stage.
@@ -500,11 +366,6 @@ __global__ void __launch_bounds__(256) taylor_reduce_wide_kernel(int nproma, int
     const int f = t - 10 * kTaylorLambdas;
     for (int il = 0; il < kTaylorLambdas; ++il) sums[(((long long)il * nblocks + ibl) * 10 + f) * 2 + 1] = r * lam.v[il];
   }
-}
-
-__device__ __forceinline__ void atomic_max_pos(double* addr, double v) {
-  // v >= 0: the IEEE bit pattern of non-negative doubles orders like unsigned integers
-  atomicMax((unsigned long long*)addr, (unsigned long long)__double_as_longlong(v));
 }
 
 // Adjoint-test norms (cloudsc_driver_ad_mod.F90:184-195,240-264): lane = column, level sums in registers
@@ -781,7 +642,7 @@ int cloudsc2_nl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
     return fail(CLOUDSC2_EINVAL, "pert_lambda != 0 with LPHYLIN = 0: the perturbed runs of the Taylor test exist in the LPHYLIN form only");
   args.g.fair = nl_fair(g.ncols_pad, args.c.evap != 0);
   if (fits_off32(g, nproma, nlev, {s.full, s.half, s.cml, s.clv, s.loc, (long long)zero_plane.block_stride})) f |= C2F_OFF32;
-  return launch_variant(g_nl_kernels[f], args, g.ncols_pad, (hipStream_t)stream);
+  return launch_variant(nl_variant(f), args, g.ncols_pad, (hipStream_t)stream);
 }
 
 // pert_in == NULL: the increments are 0.01*x of the trajectory inputs (supsat_inc * PSUPSAT for PSUPSAT), C2F_SELFINC
@@ -793,6 +654,9 @@ static int tl_launch_impl(const cloudsc2_params* prm, double ptsphy, int nproma,
   int rc = check_geom(prm, nproma, nlev, ngptot, g);
   if (rc) return rc;
   if (!traj_in || !traj_out || !pert_out) return fail(CLOUDSC2_EINVAL, "NULL argument block");
+#if C2_TL_DMA
+  if (nproma != 128) return fail(CLOUDSC2_EINVAL, "this experiment build (C2_TL_DMA) runs the TL sweep for NPROMA 128 only");
+#endif
   Strides s = {0, 0, 0, 0, 0}, sp = {0, 0, 0, 0, 0};
   InPtrs ip, dip; OutPtrs op, dop;
   if ((rc = resolve_in(*traj_in, false, s, ip))) return rc;
@@ -827,7 +691,7 @@ static int tl_launch_impl(const cloudsc2_params* prm, double ptsphy, int nproma,
   // -3.7 % at 160 000 columns with the waves kept abreast; the fp64 TL and both adjoints run one wave per SIMD and lose 1-5 %
   // (profiles/r03_wave_times.txt)
   if (sizeof(real_t) == 4 && (f & C2F_OFF32) && !(f & C2F_EVAP)) args.g.fair = nl_fair(g.ncols_pad, false);
-  return launch_variant(g_tl_kernels[f], args, g.ncols_pad, (hipStream_t)stream);
+  return launch_variant(tl_variant(f), args, g.ncols_pad, (hipStream_t)stream);
 }
 
 int cloudsc2_tl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
@@ -890,13 +754,13 @@ static int ad_launch_impl(const cloudsc2_params* prm, double ptsphy, int nproma,
                                   (long long)nproma * nlev /* scratch */})) f |= C2F_OFF32;
   // the trajectory pass as a kernel of its own: the NL sweep, with the cover checkpoint when the evaporation branch is on
   const unsigned f_fwd = (f & ~C2F_ASSIGN) | (args.nl.c.evap ? C2F_CKPT : 0u);
-  if (which == 1) return launch_variant(g_nl_kernels[f_fwd], args.nl, g.ncols_pad, (hipStream_t)stream);
-  if (which == 2) return launch_variant(g_ad_reverse_kernels[f], args, g.ncols_pad, (hipStream_t)stream);
+  if (which == 1) return launch_variant(nl_variant(f_fwd), args.nl, g.ncols_pad, (hipStream_t)stream);
+  if (which == 2) return launch_variant(ad_reverse_variant(f), args, g.ncols_pad, (hipStream_t)stream);
   const bool fused = C2_AD_FUSED == 1 || (C2_AD_FUSED == 2 && g.ncols_pad > kAdSplitBelow);
-  if (fused) return launch_variant(g_ad_kernels[f], args, g.ncols_pad, (hipStream_t)stream);
+  if (fused) return launch_variant(ad_variant(f), args, g.ncols_pad, (hipStream_t)stream);
   // trajectory pass, then the reverse pass, in stream order
-  if ((rc = launch_variant(g_nl_kernels[f_fwd], args.nl, g.ncols_pad, (hipStream_t)stream))) return rc;
-  return launch_variant(g_ad_reverse_kernels[f], args, g.ncols_pad, (hipStream_t)stream);
+  if ((rc = launch_variant(nl_variant(f_fwd), args.nl, g.ncols_pad, (hipStream_t)stream))) return rc;
+  return launch_variant(ad_reverse_variant(f), args, g.ncols_pad, (hipStream_t)stream);
 }
 
 int cloudsc2_ad_launch(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
@@ -1059,7 +923,7 @@ int cloudsc2_taylor_sweep_launch(const cloudsc2_params* prm, double ptsphy, int 
   if (fits_off32(g, nproma, nlev, {s.full, s.half, s.cml, s.clv, s.loc})) f |= C2F_OFF32;
   const long long nwaves = (g.ncols_pad + kTaylorCols - 1) / kTaylorCols;
   const long long per8 = 8LL * kBlock;  // the kernel's XCD mapping wants a multiple of 8 blocks
-  if ((rc = launch_variant(g_taylor_kernels[f], args, (nwaves * 64 + per8 - 1) / per8 * per8, (hipStream_t)stream))) return rc;
+  if ((rc = launch_variant(taylor_variant(f), args, (nwaves * 64 + per8 - 1) / per8 * per8, (hipStream_t)stream))) return rc;
   const long long nblocks_stat = ((long long)ngptot + nproma_stat - 1) / nproma_stat;
   if (nproma_stat <= 512) {
     hipLaunchKernelGGL(taylor_reduce_kernel, dim3((unsigned)nblocks_stat), dim3(128), 0, (hipStream_t)stream, nproma_stat, ngptot,

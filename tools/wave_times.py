@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """When do the waves of one NL launch start and finish, and where do they run?  Needs a diagnostic build of the library:
-    hipcc <CXXFLAGS of csrc/Makefile> -DC2_WAVE_TIMES -shared -o /tmp/wt.so csrc/cloudsc2_kernels.hip
+    hipcc <CXXFLAGS of csrc/Makefile> -DC2_WAVE_TIMES -DC2_SINGLE_TU -shared -o /tmp/wt.so csrc/cloudsc2_kernels.hip
     CLOUDSC2_LIB=/tmp/wt.so python tools/wave_times.py [NGPTOT [NPROMA [nl|tl|ad|ad_reverse]]]
 Prints the distribution of the waves' start and end times (microseconds after the first wave's start; 100 MHz clock, 10 ns
 resolution) for a launch in steady state, per XCD and per number of waves sharing a SIMD."""
