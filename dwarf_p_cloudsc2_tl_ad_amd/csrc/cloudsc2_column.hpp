@@ -610,37 +610,6 @@ C2_HD void self_increment(const RawLevel& r, real_t supsat_inc, RawLevel& d) {
   d.gl = r.gl * e; d.gi = r.gi * e; d.supsat = r.supsat * supsat_inc;
 }
 
-// -DC2_TL_PARK=1 (experiment, profiles/EXPERIMENTS.md section 6; default off): the look-ahead sets of the TL sweep -- the 32 inputs of
-// level jk+1, requested at the top of level jk -- are PARKED in LDS once level_forward has run (they have had its time to arrive) and
-// read back after the level's stores, so that they hold no registers during level_tl, where the pressure peaks: 16 KiB of LDS per wave
-// (8 waves per CU fit the 160 KiB), 32 ds_write_b64 + 32 ds_read_b64 per level and wave.  The pointer is laundered on both sides: the
-// compiler must not forward the stored values to the loads through registers, which is the whole point.
-#ifndef C2_TL_PARK
-#define C2_TL_PARK 0
-#endif
-#if C2_TL_PARK && defined(__HIP_DEVICE_COMPILE__)
-constexpr int kParkSlots = 32;
-typedef __attribute__((address_space(3))) real_t lds_real_t;
-__device__ __forceinline__ lds_real_t* park_base() {
-  __shared__ real_t park[kParkSlots][128];
-  lds_real_t* p = (lds_real_t*)&park[0][threadIdx.x];
-  asm volatile("" : "+v"(p));
-  return p;
-}
-__device__ __forceinline__ void park_put(lds_real_t* p, int k0, const RawLevel& r) {
-  const real_t v[16] = {r.paph_k1, r.pap, r.q, r.qsat, r.t, r.l, r.i, r.lude, r.lu_k1, r.mfu, r.mfd, r.gt, r.gq, r.gl, r.gi, r.supsat};
-#pragma unroll
-  for (int k = 0; k < 16; ++k) p[(k0 + k) * 128] = v[k];
-}
-__device__ __forceinline__ void park_get(const lds_real_t* p, int k0, RawLevel& r) {
-  real_t v[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) v[k] = p[(k0 + k) * 128];
-  r.paph_k1 = v[0]; r.pap = v[1]; r.q = v[2]; r.qsat = v[3]; r.t = v[4]; r.l = v[5]; r.i = v[6]; r.lude = v[7]; r.lu_k1 = v[8];
-  r.mfu = v[9]; r.mfd = v[10]; r.gt = v[11]; r.gq = v[12]; r.gl = v[13]; r.gi = v[14]; r.supsat = v[15];
-}
-#endif
-
 // ---------------------------------------------------------------------------------------------------------
 // TL: SATUR (optionally fused) + CLOUDSC2TL for one column
 // ---------------------------------------------------------------------------------------------------------
@@ -712,14 +681,6 @@ C2_HD void tl_column(long long gcol, TlArgsP a) {
     LevelTraj tr;
     LevelOut lo, dlo;
     level_forward<P, EVAP>(c, k, rh, x, cy, tr, lo);
-#if C2_TL_PARK && defined(__HIP_DEVICE_COMPILE__)
-    const real_t cur_paph_k1 = cur.paph_k1, dcur_paph_k1 = dcur.paph_k1;
-    if (!last) {
-      lds_real_t* pk = park_base();
-      park_put(pk, 0, nxt);
-      if (!SELFINC) park_put(pk, 16, dnxt);
-    }
-#endif
     level_tl(c, k, x, tr, dx, dcy, dlo);
     C2_LAUNDER(ap);
     out = &ap->out; dout = &ap->dout;
@@ -730,18 +691,9 @@ C2_HD void tl_column(long long gcol, TlArgsP a) {
             (double)dlo.clc * dlo.clc + (double)dlo.covptot * dlo.covptot + (double)dlo.fplsl * dlo.fplsl + (double)dlo.fplsn * dlo.fplsn +
             (double)dlo.fhpsl * dlo.fhpsl + (double)dlo.fhpsn * dlo.fhpsn;
     }
-#if C2_TL_PARK && defined(__HIP_DEVICE_COMPILE__)
-    paph_k = cur_paph_k1; dpaph_k = dcur_paph_k1;
-    if (!last) {
-      const lds_real_t* pk = park_base();
-      park_get(pk, 0, cur);
-      if (!SELFINC) park_get(pk, 16, dcur);
-    }
-#else
     paph_k = cur.paph_k1; dpaph_k = dcur.paph_k1;
     cur = nxt;
     if (!SELFINC) dcur = dnxt;
-#endif
   }
   if (SELFINC) {
     double* p = a->yy;

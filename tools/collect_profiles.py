@@ -26,7 +26,9 @@ if os.path.exists(os.path.join(src, "timed_kernel_stats.csv")):  # one row per t
         for f in glob.glob(os.path.join(d, "*", "*kernel_stats.csv")):
             shutil.copy(f, os.path.join(dst, f"{prefix}_{os.path.basename(d)[5:]}_kernel_stats.csv"))
     for f in glob.glob(os.path.join(src, "bench_prof_*_*.json")):
-        shutil.copy(f, os.path.join(dst, f"{prefix}_{os.path.basename(f)[6:-5]}_under_rocprof.json"))
+        name = os.path.basename(f)[len("bench_prof_"):-len(".json")]
+        if name.split("_")[0] in ("tl", "ad", "adrev", "selftests"):  # (the NL runs are copied above under their older names)
+            shutil.copy(f, os.path.join(dst, f"{prefix}_{name}_under_rocprof.json"))
 if os.path.exists(os.path.join(src, "pytest_gpu.log")):
     cp("pytest_gpu.log", "pytest_gpu.log")
 for opt in ("rocm_smi_during_bench.txt", "single_checks_gpu.log"):
