@@ -6,6 +6,12 @@ in HBM.  Weak scaling: every rank owns its own 160000-column sub-range of the gl
 split); there is no collective in the data path.  Prints ONE JSON line (rank 0).  `--gpus N` without a launcher starts
 the N ranks itself; under `python -m torch.distributed.run` it uses the launcher's ranks.
 
+N > 1 (first exercised on hardware by the driver's scaling run): the time of a rank is its own K steps (synchronize on both sides,
+a barrier before and after), `value` = all ranks' columns / the MAX over ranks.  Rank 0 prints the timing line -- every field of the
+contract -- as soon as that MAX is known, and the full line (the same plus the self-tests' verdicts reduced over the ranks) LAST, so
+that a run that ends in the verdict legs still leaves its measurement on stdout; `python bench.py --gpus N` (own launcher) relays
+only the last line.  `--budget-s` (420) bounds the whole launch and, by a fraction of at most 120 s, every rendezvous / collective.
+
 The state is the first and only allocation of the process and comes from the library's allocator, which places it
 (cloudsc2_device_malloc_state: candidate allocations judged by the NL sweep itself; profiles/r02_hbm_placement.md): bench.py does
 not search.  `roofline.unplaced_first_allocation`
@@ -471,10 +477,9 @@ def main():
         step()
         b.record(stream)
     torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0  # this rank's K steps, device work included; the closing barrier follows, then the MAX over ranks
     if world > 1:
         barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
         elapsed = float(c2dist.allreduce_max([elapsed], dev)[0])  # MAX over ranks (RCCL all-reduce of one double)
     kms = np.array([a.elapsed_time(b) for a, b in ev])  # per-launch device time on the launch stream
     ms_per_step = elapsed / args.steps * 1e3
