@@ -19,8 +19,9 @@ is the same measurement in a fresh process with the placement switched off.
 
 The line also carries `cpu_baseline` (the reference on the host cores, rank 0 at N=1) and, at N=1, from child processes run
 after the measurement: `companion_kernels` (the same bench for TL and AD -- BASELINE.json's metric names all three),
-`target_config` (NL at 1 048 576 columns, north_star's target) and `self_tests` (the Taylor test and the adjoint test on a resident
-state of the same size: verdicts and kernel time); none of them is inside the timed region.
+`target_config` (NL at 1 048 576 columns, north_star's target), `host_array_driver` (the PCIe-inclusive rate of the reference-signature
+path, never `value`) and `self_tests` (the Taylor test and the adjoint test on a resident state of the same size: verdicts and kernel
+time); none of them is inside the timed region.
 """
 from __future__ import annotations
 
@@ -329,6 +330,9 @@ def main():
     ap.add_argument("--self-tests", action="store_true",
                     help="no bench line: the reference's two self-tests (CLOUDSC_DRIVER_TL's Taylor test, CLOUDSC_DRIVER_AD's adjoint test) on "
                          "a resident state of --ngptot columns, with their verdicts and the kernel time of the whole driver call")
+    ap.add_argument("--host-driver-rate", action="store_true",
+                    help="no bench line: the PCIe-inclusive rate of the reference-signature path -- cloudsc2_nl_run, what CLOUDSC_DRIVER binds, "
+                         "on host arrays in pageable memory (upload, kernel, download per call); reported beside `value`, never as `value`")
     ap.add_argument("--budget-s", type=float, default=420.0,
                     help="N > 1: everything must be over inside this many seconds (the driver kills a run at 600 s and then nothing is "
                          "written): the launcher's overall deadline, and -- a fraction of it, at most 120 s -- the timeout of the "
@@ -384,6 +388,26 @@ def main():
         res["adjoint_test"] = {"kernel_ms": min(x[2] for x in a[1:]), "passed": bool(a[-1][1]), "znormg_in_eps": float(a[-1][0]),
                                "what": "SATUR, TL sweep forming <y,y>, reverse sweep alone (assign form) forming <x0,x_adj> and norm3"}
         print(json.dumps(res), flush=True)
+        return
+
+    if args.host_driver_rate:
+        if not c2.device_available():
+            raise SystemExit("bench.py needs a HIP device: the CLOUDSC2 engine has no CPU path")
+        tab = c2.synthetic_table()
+        prm = c2.default_params(c2.ceta_from_table(tab))
+        st = c2.state_from_table(tab, args.nproma, args.ngptot)
+        walls, kms = [], []
+        for _ in range(4):  # the first call allocates the workspace (one plain hipMalloc) and pages the host arrays in
+            t0 = time.perf_counter()
+            k = c2.run_state(prm, st, "nl")
+            walls.append(time.perf_counter() - t0)
+            kms.append(float(k))
+        w = float(np.median(walls[1:]))
+        print(json.dumps({"entry_point": "cloudsc2_nl_run (what CLOUDSC_DRIVER binds): host arrays in pageable memory, 17.5 KB up + 12.1 KB down per column, "
+                                         "slabs of 16 384 columns with upload / kernel / download overlapped",
+                          "ngptot": args.ngptot, "nproma": args.nproma, "ms_per_call": w * 1e3, "columns_per_s": args.ngptot / w,
+                          "kernel_ms_sum_over_slabs": float(np.median(kms[1:])), "first_call_ms": walls[0] * 1e3,
+                          "note": "PCIe-bound; never `value` -- the resident state is what the kernel's rate needs"}), flush=True)
         return
 
     if args.rendezvous_only:
@@ -581,6 +605,11 @@ def main():
                                                             "note": "fresh process, CLOUDSC2_PLACE=0: plain first hipMalloc"}
         except Exception as e:  # noqa: BLE001
             out["roofline"]["unplaced_first_allocation"] = {"error": repr(e)}
+        # (3b) what the UNCHANGED caller of CLOUDSC_DRIVER gets: host arrays through cloudsc2_nl_run, PCIe included
+        try:
+            out["host_array_driver"] = child_bench(["--host-driver-rate", "--ngptot", args.ngptot, "--nproma", args.nproma, "--precision", args.precision])
+        except Exception as e:  # noqa: BLE001
+            out["host_array_driver"] = {"error": repr(e)}
         # (4) the reference's two self-tests on a resident state of the same size: verdicts and the kernel time of the whole driver call
         try:
             out["self_tests"] = child_bench(["--self-tests", "--ngptot", args.ngptot, "--nproma", args.nproma, "--precision", args.precision])

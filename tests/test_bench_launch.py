@@ -163,3 +163,5 @@ def test_without_a_gpu_the_bench_fails_loudly():
     assert r.returncode != 0 and "no CPU path" in (r.stderr + r.stdout)
     r = _run(["--self-tests", "--ngptot", 100])  # the two self-tests on a resident state: the same refusal
     assert r.returncode != 0 and "no CPU path" in (r.stderr + r.stdout)
+    r = _run(["--host-driver-rate", "--ngptot", 100])  # and the host-array driver's rate
+    assert r.returncode != 0 and "no CPU path" in (r.stderr + r.stdout)

@@ -57,3 +57,13 @@ def test_two_ranks_on_one_gpu_rehearse_the_multi_gpu_path(tmp_path):
     assert len(d["roofline"]["kernel_ms_avg_per_rank"]) == 2
     v = d["verdicts"]
     assert v["backend"] == "gloo" and v["tl_passed"] and v["ad_ok"] and len(v["tl_znormg"]) == 10, v
+
+
+def test_host_array_driver_rate_is_reported_beside_the_value():
+    """What an unchanged caller of CLOUDSC_DRIVER gets (host arrays through cloudsc2_nl_run, PCIe included) -- a companion of the
+    line, never `value`."""
+    r = _bench(["--host-driver-rate", "--ngptot", 32768])
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["ngptot"] == 32768 and d["columns_per_s"] > 1e5 and d["ms_per_call"] > d["kernel_ms_sum_over_slabs"] > 0.0
+    assert "cloudsc2_nl_run" in d["entry_point"] and "value" not in d
