@@ -754,9 +754,12 @@ static int ad_launch_impl(const cloudsc2_params* prm, double ptsphy, int nproma,
                                   (long long)nproma * nlev /* scratch */})) f |= C2F_OFF32;
   // the trajectory pass as a kernel of its own: the NL sweep, with the cover checkpoint when the evaporation branch is on
   const unsigned f_fwd = (f & ~C2F_ASSIGN) | (args.nl.c.evap ? C2F_CKPT : 0u);
+  // as a kernel of its own the trajectory pass is the NL kernel at its three waves per SIMD: keep them abreast like cloudsc2_nl_launch
+  // does (inside the fused kernel, one wave per SIMD, the priority code is compiled out)
+  const bool fused = which == 0 && (C2_AD_FUSED == 1 || (C2_AD_FUSED == 2 && g.ncols_pad > kAdSplitBelow));
+  if (!fused && which != 2) args.nl.g.fair = nl_fair(g.ncols_pad, args.nl.c.evap != 0);
   if (which == 1) return launch_variant(nl_variant(f_fwd), args.nl, g.ncols_pad, (hipStream_t)stream);
   if (which == 2) return launch_variant(ad_reverse_variant(f), args, g.ncols_pad, (hipStream_t)stream);
-  const bool fused = C2_AD_FUSED == 1 || (C2_AD_FUSED == 2 && g.ncols_pad > kAdSplitBelow);
   if (fused) return launch_variant(ad_variant(f), args, g.ncols_pad, (hipStream_t)stream);
   // trajectory pass, then the reverse pass, in stream order
   if ((rc = launch_variant(nl_variant(f_fwd), args.nl, g.ncols_pad, (hipStream_t)stream))) return rc;
