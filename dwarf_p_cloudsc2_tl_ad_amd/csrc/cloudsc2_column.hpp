@@ -28,6 +28,8 @@ struct Geom {
   long long ncols_pad;  // NBLOCKS*NPROMA
   int kb0, kb1;         // tropopause band [kb0,kb1): levels that can satisfy 0.1 < CETA < 0.4 (cloudsc2.F90:320)
   int fair;             // NL: the waves of a SIMD yield to each other by progress (progress_priority); set by the launcher
+  // TL / AD: pacing of a launch of a few partial rounds of workgroups (struct Pace below); pace_recip_q16 = 0: off
+  int pace_slots = 0, pace_first = 0, pace_recip_q16 = 0;
 };
 
 // Fields are grouped by the stride between NPROMA blocks.  `full` = (NPROMA,NLEV,NBLOCKS) arrays,
@@ -610,6 +612,43 @@ C2_HD void self_increment(const RawLevel& r, real_t supsat_inc, RawLevel& d) {
   d.gl = r.gl * e; d.gi = r.gi * e; d.supsat = r.supsat * supsat_inc;
 }
 
+// Pacing of the TL / AD sweeps when a launch is a few PARTIAL rounds of workgroups (round 4; profiles/EXPERIMENTS.md section 7).
+// 160 000 columns are 1250 workgroups on 512 workgroup slots (256 CUs x 4 SIMDs at one wave per SIMD, two waves per workgroup): 226
+// slots process three workgroups, 286 two, and the launch lasts as long as the three -- the third alone on a machine the others have
+// left, at a lone wave's latency-bound pace.  While all slots are busy the memory system is saturated and every wave is slowed alike,
+// but only the three-workgroup slots are on the critical path.  With in-order dispatch the workgroups that will share a slot with
+// k others (instead of k - 1) are known in advance: position p = blockIdx mod slots of a round is in the FAST class if
+// p < (workgroups mod slots).  The others nap at every level for 1/k of the time the level took them: their slot then needs the time
+// of k + 1 unpaced workgroups for its k, they leave their share of the bandwidth to the fast class, and both classes end together
+// (TL at 160 000 columns: 1.65 -> 1.57 ms, AD 3.01 -> 2.83 ms).  The nap is measured, not tabulated: it follows the clock, the
+// variant and the contention by itself.
+// Pace: state of one wave (wave-uniform scalars); begin() before the level loop, nap() once per level with the next loads in flight.
+struct Pace {
+  unsigned recip_q16 = 0;  // 65536 / k for the slow class, 0 = this workgroup does not nap
+  unsigned mark = 0;       // shader clock (low 32 bits) when the previous nap ended
+  C2_HD void begin(GeomP g) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned r = (unsigned)g->pace_recip_q16;
+    if (r == 0) return;
+    unsigned b = blockIdx.x;
+    const unsigned s = (unsigned)g->pace_slots;
+    while (b >= s) b -= s;  // (at most eight rounds: the launcher paces short launches only)
+    if (b >= (unsigned)g->pace_first) { recip_q16 = r; mark = (unsigned)__builtin_amdgcn_s_memtime(); }
+#else
+    (void)g;
+#endif
+  }
+  C2_HD void nap() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (recip_q16 == 0) return;
+    const unsigned work = (unsigned)__builtin_amdgcn_s_memtime() - mark;             // clocks since the previous nap ended
+    const unsigned naps = (unsigned)(((unsigned long long)work * recip_q16) >> 22);    // work / k, in units of 64 clocks
+    for (unsigned i = 0; i < naps && i < 512u; ++i) __builtin_amdgcn_s_sleep(1);
+    mark = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
+  }
+};
+
 // ---------------------------------------------------------------------------------------------------------
 // TL: SATUR (optionally fused) + CLOUDSC2TL for one column
 // ---------------------------------------------------------------------------------------------------------
@@ -653,6 +692,8 @@ C2_HD void tl_column(long long gcol, TlArgsP a) {
   const LaneOffT<OT> ol = lane_off_as<OT>(o), opl = lane_off_as<OT>(op);  // offsets used inside the level loop
   load_level<HAS_QSAT>(in, ol, nproma, nlev, 0, cur);
   if (!SELFINC) load_level<true>(din, opl, nproma, nlev, 0, dcur);
+  Pace pace;
+  pace.begin(&a->g);
 
   // Both input sets of level jk+1 are requested at the top of level jk.  Measured alternatives (profiles/r02_ab_experiments.txt):
   // requesting the perturbation inputs at the top of their own level (no second register set for them: 280 instead of 311
@@ -670,6 +711,7 @@ C2_HD void tl_column(long long gcol, TlArgsP a) {
       load_level<HAS_QSAT>(in, ol, nproma, nlev, jk + 1, nxt);
       if (!SELFINC) load_level<true>(din, opl, nproma, nlev, jk + 1, dnxt);
     }
+    pace.nap();  // (with the next level's loads in flight)
     if (!HAS_QSAT) cur.qsat = satur_point<P>(c, cur.pap, cur.t);
     if (SELFINC) self_increment(cur, ap->supsat_inc, dcur);
 
@@ -959,8 +1001,11 @@ C2_HD double ad_reverse_column(long long gcol, AdArgsP a) {  // returns |norm3| 
   real_t paph_k1 = paph_bottom;
   double n2 = 0.0;  // ADNORM: <x0, x_adj>, x0 = 0.01 * trajectory inputs, ZSUPSAT0 = 0 (cloudsc_driver_ad_mod.F90:139,240-256)
   AdLevelLoads L;
+  Pace pace;
+  pace.begin(&a->nl.g);
   for (int jk = nlev - 1; jk >= 0; --jk) {
     const bool last = (jk == nlev - 1);
+    pace.nap();
     const OT d = level_off(OT(), jk, nproma);
     const OT d1 = d + row_off(OT(), nproma);
     AdArgsP ap = a;

@@ -23,6 +23,7 @@
 #include <stddef.h>
 #include <string>
 #include <thread>
+#include <tuple>
 #include <utility>
 #include <vector>
 
@@ -493,6 +494,53 @@ int nl_fair(long long ncols_pad, bool evap) {
   return waves <= slots;
 }
 
+// Pacing of a TL / AD launch (cloudsc2_column.hpp: struct Pace): on when the launch is two to eight whole rounds of workgroups on the
+// slots the device has for THIS kernel (its occupancy, asked of the runtime once per kernel and device) plus a partial round that
+// fills at most half of them.
+// CLOUDSC2_PACE=0 switches it off (measurements).
+template <class Args>
+void set_pace(Geom& g, KernelFn<Args> fn) {
+  g.pace_slots = g.pace_first = g.pace_recip_q16 = 0;
+  static const bool off = getenv("CLOUDSC2_PACE") && atoi(getenv("CLOUDSC2_PACE")) == 0;
+  if (off || !fn) return;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return; }
+  static std::mutex mu;
+  static std::vector<std::tuple<const void*, int, long long>> cache;  // (kernel, device) -> workgroup slots
+  long long slots = 0;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto& e : cache)
+      if (std::get<0>(e) == (const void*)fn && std::get<1>(e) == dev) slots = std::get<2>(e);
+    if (!slots) {
+      int cus = 0, per_cu = 0;
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)fn, kBlock, 0) != hipSuccess || cus <= 0 || per_cu <= 0) {
+        (void)hipGetLastError();
+        return;
+      }
+      slots = (long long)cus * per_cu;
+      cache.emplace_back((const void*)fn, dev, slots);
+    }
+  }
+  const long long wgs = (g.ncols_pad + kBlock - 1) / kBlock, k = wgs / slots, rem = wgs % slots;
+  // Where it pays (profiles/r04_pacing_ab.txt, TL / AD in % of time; k whole rounds, f = the partial round's share of the slots):
+  //   k 2 f 0.14: -7.7 / -6.0   k 2 f 0.44 (160 000 columns): -4.9 / -7.6   k 3 f 0.05: -7.6 / -8.0   k 5 f 0.04: -1.7 / -7.1
+  //   k 6 f 0.10: -0.9 / -6.9   but k 1 f 0.53: +2.3 / +2.8   k 1 f 0.83: +1.8 / +0.5   k 2 f 0.75: +1.9 / +0.5
+  //   k 3 f 0.82: +1.3 / +0.7   k 4 f 0.58: +2.6 / -1.8
+  // i.e. at least two whole rounds and a partial round that leaves half of the machine or more idle; beyond eight rounds the
+  // imbalance is a few per cent of the launch and the sweeps are left alone.  CLOUDSC2_PACE_KMIN / _KMAX / _FMAX move the limits.
+  static const long long kmin = getenv("CLOUDSC2_PACE_KMIN") ? atoll(getenv("CLOUDSC2_PACE_KMIN")) : 2;
+  static const long long kmax = getenv("CLOUDSC2_PACE_KMAX") ? atoll(getenv("CLOUDSC2_PACE_KMAX")) : 8;
+  static const double fmax = getenv("CLOUDSC2_PACE_FMAX") ? atof(getenv("CLOUDSC2_PACE_FMAX")) : 0.5;
+  if (k < kmin || k > kmax || rem == 0 || (double)rem > fmax * (double)slots) return;
+  g.pace_slots = (int)slots; g.pace_first = (int)rem; g.pace_recip_q16 = (int)(65536 / k);
+  static const bool verbose = getenv("CLOUDSC2_PACE_VERBOSE") != nullptr;
+  if (verbose)
+    fprintf(stderr, "cloudsc2: launch of %lld workgroups on %lld slots paced: %lld whole rounds + %lld workgroups; the other %lld slots nap 1/%lld of every level\n",
+            wgs, slots, k, rem, slots - rem, k);
+}
+
 // 32-bit byte offsets (C2F_OFF32) are usable when every buffer the sweep touches is smaller than 4 GiB
 bool fits_off32(const Geom& g, int nproma, int nlev, std::initializer_list<long long> strides) {
   static const bool allow32 = !(getenv("CLOUDSC2_OFF32") && atoi(getenv("CLOUDSC2_OFF32")) == 0);  // 0: measurements only
@@ -691,6 +739,7 @@ static int tl_launch_impl(const cloudsc2_params* prm, double ptsphy, int nproma,
   // -3.7 % at 160 000 columns with the waves kept abreast; the fp64 TL and both adjoints run one wave per SIMD and lose 1-5 %
   // (profiles/r03_wave_times.txt)
   if (sizeof(real_t) == 4 && (f & C2F_OFF32) && !(f & C2F_EVAP)) args.g.fair = nl_fair(g.ncols_pad, false);
+  else set_pace(args.g, tl_variant(f));
   return launch_variant(tl_variant(f), args, g.ncols_pad, (hipStream_t)stream);
 }
 
@@ -759,6 +808,7 @@ static int ad_launch_impl(const cloudsc2_params* prm, double ptsphy, int nproma,
   const bool fused = which == 0 && (C2_AD_FUSED == 1 || (C2_AD_FUSED == 2 && g.ncols_pad > kAdSplitBelow));
   if (!fused && which != 2) args.nl.g.fair = nl_fair(g.ncols_pad, args.nl.c.evap != 0);
   if (which == 1) return launch_variant(nl_variant(f_fwd), args.nl, g.ncols_pad, (hipStream_t)stream);
+  set_pace(args.nl.g, (which == 2 || !fused) ? ad_reverse_variant(f) : ad_variant(f));
   if (which == 2) return launch_variant(ad_reverse_variant(f), args, g.ncols_pad, (hipStream_t)stream);
   if (fused) return launch_variant(ad_variant(f), args, g.ncols_pad, (hipStream_t)stream);
   // trajectory pass, then the reverse pass, in stream order
