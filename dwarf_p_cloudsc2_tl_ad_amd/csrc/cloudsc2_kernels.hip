@@ -534,7 +534,8 @@ void set_pace(Geom& g, KernelFn<Args> fn) {
   static const long long kmax = getenv("CLOUDSC2_PACE_KMAX") ? atoll(getenv("CLOUDSC2_PACE_KMAX")) : 8;
   static const double fmax = getenv("CLOUDSC2_PACE_FMAX") ? atof(getenv("CLOUDSC2_PACE_FMAX")) : 0.5;
   if (k < kmin || k > kmax || rem == 0 || (double)rem > fmax * (double)slots) return;
-  g.pace_slots = (int)slots; g.pace_first = (int)rem; g.pace_recip_q16 = (int)(65536 / k);
+  static const double scale = getenv("CLOUDSC2_PACE_SCALE") ? atof(getenv("CLOUDSC2_PACE_SCALE")) : 1.0;  // (measurements: nap = scale / k of a level)
+  g.pace_slots = (int)slots; g.pace_first = (int)rem; g.pace_recip_q16 = (int)(scale * 65536.0 / (double)k);
   static const bool verbose = getenv("CLOUDSC2_PACE_VERBOSE") != nullptr;
   if (verbose)
     fprintf(stderr, "cloudsc2: launch of %lld workgroups on %lld slots paced: %lld whole rounds + %lld workgroups; the other %lld slots nap 1/%lld of every level\n",
