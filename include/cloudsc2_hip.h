@@ -170,7 +170,13 @@ int cloudsc2_satur_launch(const cloudsc2_params* prm, int nproma, int nlev, int 
 
 /* CLOUDSC2TL (src/cloudsc2_tl/cloudsc2tl.F90:10-24): trajectory in -> trajectory out (give all ten traj_out
  * fields, or all NULL to skip the trajectory stores), perturbation in -> perturbation out.  traj_in->qsat NULL => fused
- * SATUR for PQS5.  pert_in must give all 16 fields. */
+ * SATUR for PQS5.  pert_in must give all 16 fields.
+ * Launch pacing (TL and AD sweeps; results unaffected): these kernels run one wave per SIMD, so a launch is a number of rounds of
+ * workgroups on the device's slots; when it is two to eight whole rounds plus a partial one that fills at most half of the slots
+ * (160 000 columns on MI355X: 1250 workgroups on 512 slots), the workgroups whose slot has one workgroup less to run nap at every
+ * level for 1/k of the level's measured time, leaving their share of the bandwidth to the slots on the critical path: TL -5 %, AD
+ * -7 % at 160 000 columns (profiles/r04_pacing_ab.txt).  CLOUDSC2_PACE=0 in the environment switches it off,
+ * CLOUDSC2_PACE_VERBOSE=1 reports paced launches on stderr. */
 int cloudsc2_tl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
                        const cloudsc2_inputs* traj_in, const cloudsc2_outputs* traj_out,
                        const cloudsc2_inputs* pert_in, const cloudsc2_outputs* pert_out, void* stream);
