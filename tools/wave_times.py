@@ -65,7 +65,22 @@ for rep in range(5):
     for v in per_simd.values():
         for k, (a_, b_) in enumerate(v):
             nth.setdefault(k, []).append((a_, b_, b_ - a_))
-    r = {"event_ms": ev0.elapsed_time(ev1), "kernel": kind,
+    # the pacing rule's prediction (cloudsc2_kernels.hip: set_pace; one wave per SIMD: 2 waves per workgroup, CUs x 2 slots): workgroups
+    # at position p < rem of a round are expected on the slots that run one workgroup more -- checked against where they really ran
+    pace = None
+    if kind != "nl":
+        idx = np.nonzero(ok)[0]
+        wg = idx // 2
+        slots = 2 * torch.cuda.get_device_properties(0).multi_processor_count
+        nwg = nwaves // 2
+        k_rounds, rem = nwg // slots, nwg % slots
+        fast = (wg % slots) < rem
+        pace = {"slots": slots, "whole_rounds": int(k_rounds), "partial_round": int(rem),
+                "fast_class_waves_by_waves_on_their_simd": {int(k): int(((share == k) & fast).sum()) for k in np.unique(share)},
+                "slow_class_waves_by_waves_on_their_simd": {int(k): int(((share == k) & ~fast).sum()) for k in np.unique(share)},
+                "end_us_fast_class_p50_p100": [round(float(np.median(end[fast])), 1), round(float(end[fast].max()), 1)] if fast.any() else None,
+                "end_us_slow_class_p50_p100": [round(float(np.median(end[~fast])), 1), round(float(end[~fast].max()), 1)] if (~fast).any() else None}
+    r = {"event_ms": ev0.elapsed_time(ev1), "kernel": kind, "pace_rule_vs_reality": pace,
          "nth_wave_of_its_simd_start_end_duration_us_median": {k: [round(float(np.median([x[j] for x in v])), 1) for j in range(3)] + [len(v)] for k, v in sorted(nth.items()) if k < 8}, "waves": int(ok.sum()), "simds_used": int(len(uniq)),
          "start_us_p0_10_50_90_99_100": q(start), "end_us": q(end), "duration_us": q(dur),
          "waves_per_simd_hist": {int(k): int(v) for k, v in zip(*np.unique(cnt, return_counts=True))},
