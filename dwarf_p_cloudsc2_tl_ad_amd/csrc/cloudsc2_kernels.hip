@@ -498,11 +498,14 @@ int nl_fair(long long ncols_pad, bool evap) {
 // slots the device has for THIS kernel (its occupancy, asked of the runtime once per kernel and device) plus a partial round that
 // fills at most half of them.
 // CLOUDSC2_PACE=0 switches it off (measurements).
+bool device_is_shared();  // cloudsc2_alloc.inc: do other ranks use this device at the same time?
 template <class Args>
 void set_pace(Geom& g, KernelFn<Args> fn) {
   g.pace_slots = g.pace_first = g.pace_recip_q16 = 0;
   static const bool off = getenv("CLOUDSC2_PACE") && atoi(getenv("CLOUDSC2_PACE")) == 0;
   if (off || !fn) return;
+  static const bool shared = device_is_shared();  // then the slots are not this launch's alone: the rule's premise is gone
+  if (shared) return;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return; }
   static std::mutex mu;
