@@ -293,6 +293,43 @@ C2_HD void level_cst(LevelTabP tab, int jk, bool last, LevelCst& k) {
   C2_PIN2(k.ceta, k.zscalm);
 }
 
+// Pacing of the TL / AD sweeps when a launch is a few PARTIAL rounds of workgroups (round 4; profiles/EXPERIMENTS.md section 7).
+// 160 000 columns are 1250 workgroups on 512 workgroup slots (256 CUs x 4 SIMDs at one wave per SIMD, two waves per workgroup): 226
+// slots process three workgroups, 286 two, and the launch lasts as long as the three -- the third alone on a machine the others have
+// left, at a lone wave's latency-bound pace.  While all slots are busy the memory system is saturated and every wave is slowed alike,
+// but only the three-workgroup slots are on the critical path.  With in-order dispatch the workgroups that will share a slot with
+// k others (instead of k - 1) are known in advance: position p = blockIdx mod slots of a round is in the FAST class if
+// p < (workgroups mod slots).  The others nap at every level for 1/k of the time the level took them: their slot then needs the time
+// of k + 1 unpaced workgroups for its k, they leave their share of the bandwidth to the fast class, and both classes end together
+// (TL at 160 000 columns: 1.65 -> 1.57 ms, AD 3.01 -> 2.83 ms).  The nap is measured, not tabulated: it follows the clock, the
+// variant and the contention by itself.
+// Pace: state of one wave (wave-uniform scalars); begin() before the level loop, nap() once per level with the next loads in flight.
+struct Pace {
+  unsigned recip_q16 = 0;  // 65536 / k for the slow class, 0 = this workgroup does not nap
+  unsigned mark = 0;       // shader clock (low 32 bits) when the previous nap ended
+  C2_HD void begin(GeomP g) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned r = (unsigned)g->pace_recip_q16;
+    if (r == 0) return;
+    unsigned b = blockIdx.x;
+    const unsigned s = (unsigned)g->pace_slots;
+    while (b >= s) b -= s;  // (at most eight rounds: the launcher paces short launches only)
+    if (b >= (unsigned)g->pace_first) { recip_q16 = r; mark = (unsigned)__builtin_amdgcn_s_memtime(); }
+#else
+    (void)g;
+#endif
+  }
+  C2_HD void nap() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (recip_q16 == 0) return;
+    const unsigned work = (unsigned)__builtin_amdgcn_s_memtime() - mark;             // clocks since the previous nap ended
+    const unsigned naps = (unsigned)(((unsigned long long)work * recip_q16) >> 22);    // work / k, in units of 64 clocks
+    for (unsigned i = 0; i < naps && i < 512u; ++i) __builtin_amdgcn_s_sleep(1);
+    mark = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
+  }
+};
+
 // Compile-time variant flags of the column sweeps (template argument F of the functions below and of the kernels)
 enum : unsigned {
   C2F_QSAT = 1u,     // PQSAT is an input (otherwise SATUR is evaluated in the sweep)
@@ -425,6 +462,9 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
   const LaneOffT<OT> ol = lane_off_as<OT>(o);
   const OT ozl = (OT)(ozero * (OFF32 ? (long long)sizeof(real_t) : 1)), oscl = (OT)(osc * (OFF32 ? (long long)sizeof(real_t) : 1));
 
+  Pace pace;  // (the trajectory pass INSIDE the fused adjoint kernel, one wave per SIMD, naps like the reverse pass does)
+  if (CKPT) pace.begin(&a->g);
+
   // one level: `cur` holds the raw inputs of level jk (requested one level ago), `nxt` receives those of level jk+1
   auto step = [&](int jk, RawLevel& cur, RawLevel& nxt) {
     const bool last = (jk == nlev - 1);
@@ -434,6 +474,7 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
     // request everything level jk+1 needs now; nothing below touches `nxt` before the end of this level, so the
     // HBM latency is covered by the whole level's arithmetic
     if (!last) load_level<HAS_QSAT>(&ap->in, ol, nproma, nlev, jk + 1, nxt);
+    if (CKPT) pace.nap();
 
     if (!HAS_QSAT) cur.qsat = satur_point<P>(c, cur.pap, cur.t);  // SATUR on the unperturbed PAP, PT
     if (PERT) perturb_raw(cur, lam);
@@ -611,43 +652,6 @@ C2_HD void self_increment(const RawLevel& r, real_t supsat_inc, RawLevel& d) {
   d.lude = r.lude * e; d.lu_k1 = r.lu_k1 * e; d.mfu = r.mfu * e; d.mfd = r.mfd * e; d.gt = r.gt * e; d.gq = r.gq * e;
   d.gl = r.gl * e; d.gi = r.gi * e; d.supsat = r.supsat * supsat_inc;
 }
-
-// Pacing of the TL / AD sweeps when a launch is a few PARTIAL rounds of workgroups (round 4; profiles/EXPERIMENTS.md section 7).
-// 160 000 columns are 1250 workgroups on 512 workgroup slots (256 CUs x 4 SIMDs at one wave per SIMD, two waves per workgroup): 226
-// slots process three workgroups, 286 two, and the launch lasts as long as the three -- the third alone on a machine the others have
-// left, at a lone wave's latency-bound pace.  While all slots are busy the memory system is saturated and every wave is slowed alike,
-// but only the three-workgroup slots are on the critical path.  With in-order dispatch the workgroups that will share a slot with
-// k others (instead of k - 1) are known in advance: position p = blockIdx mod slots of a round is in the FAST class if
-// p < (workgroups mod slots).  The others nap at every level for 1/k of the time the level took them: their slot then needs the time
-// of k + 1 unpaced workgroups for its k, they leave their share of the bandwidth to the fast class, and both classes end together
-// (TL at 160 000 columns: 1.65 -> 1.57 ms, AD 3.01 -> 2.83 ms).  The nap is measured, not tabulated: it follows the clock, the
-// variant and the contention by itself.
-// Pace: state of one wave (wave-uniform scalars); begin() before the level loop, nap() once per level with the next loads in flight.
-struct Pace {
-  unsigned recip_q16 = 0;  // 65536 / k for the slow class, 0 = this workgroup does not nap
-  unsigned mark = 0;       // shader clock (low 32 bits) when the previous nap ended
-  C2_HD void begin(GeomP g) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const unsigned r = (unsigned)g->pace_recip_q16;
-    if (r == 0) return;
-    unsigned b = blockIdx.x;
-    const unsigned s = (unsigned)g->pace_slots;
-    while (b >= s) b -= s;  // (at most eight rounds: the launcher paces short launches only)
-    if (b >= (unsigned)g->pace_first) { recip_q16 = r; mark = (unsigned)__builtin_amdgcn_s_memtime(); }
-#else
-    (void)g;
-#endif
-  }
-  C2_HD void nap() {
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (recip_q16 == 0) return;
-    const unsigned work = (unsigned)__builtin_amdgcn_s_memtime() - mark;             // clocks since the previous nap ended
-    const unsigned naps = (unsigned)(((unsigned long long)work * recip_q16) >> 22);    // work / k, in units of 64 clocks
-    for (unsigned i = 0; i < naps && i < 512u; ++i) __builtin_amdgcn_s_sleep(1);
-    mark = (unsigned)__builtin_amdgcn_s_memtime();
-#endif
-  }
-};
 
 // ---------------------------------------------------------------------------------------------------------
 // TL: SATUR (optionally fused) + CLOUDSC2TL for one column
