@@ -462,9 +462,6 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
   const LaneOffT<OT> ol = lane_off_as<OT>(o);
   const OT ozl = (OT)(ozero * (OFF32 ? (long long)sizeof(real_t) : 1)), oscl = (OT)(osc * (OFF32 ? (long long)sizeof(real_t) : 1));
 
-  Pace pace;  // (the trajectory pass INSIDE the fused adjoint kernel, one wave per SIMD, naps like the reverse pass does)
-  if (CKPT) pace.begin(&a->g);
-
   // one level: `cur` holds the raw inputs of level jk (requested one level ago), `nxt` receives those of level jk+1
   auto step = [&](int jk, RawLevel& cur, RawLevel& nxt) {
     const bool last = (jk == nlev - 1);
@@ -474,7 +471,6 @@ C2_HD void nl_column(long long gcol, NlArgsP a) {
     // request everything level jk+1 needs now; nothing below touches `nxt` before the end of this level, so the
     // HBM latency is covered by the whole level's arithmetic
     if (!last) load_level<HAS_QSAT>(&ap->in, ol, nproma, nlev, jk + 1, nxt);
-    if (CKPT) pace.nap();
 
     if (!HAS_QSAT) cur.qsat = satur_point<P>(c, cur.pap, cur.t);  // SATUR on the unperturbed PAP, PT
     if (PERT) perturb_raw(cur, lam);

@@ -815,10 +815,8 @@ static int ad_launch_impl(const cloudsc2_params* prm, double ptsphy, int nproma,
   set_pace(args.nl.g, (which == 2 || !fused) ? ad_reverse_variant(f) : ad_variant(f));
   if (which == 2) return launch_variant(ad_reverse_variant(f), args, g.ncols_pad, (hipStream_t)stream);
   if (fused) return launch_variant(ad_variant(f), args, g.ncols_pad, (hipStream_t)stream);
-  // trajectory pass, then the reverse pass, in stream order (the pacing set above is the reverse kernel's: not the NL kernel's slots)
-  NlArgs fwd = args.nl;
-  fwd.g.pace_slots = fwd.g.pace_first = fwd.g.pace_recip_q16 = 0;
-  if ((rc = launch_variant(nl_variant(f_fwd), fwd, g.ncols_pad, (hipStream_t)stream))) return rc;
+  // trajectory pass, then the reverse pass, in stream order (the NL kernel does not look at the pacing fields: they are the reverse kernel's)
+  if ((rc = launch_variant(nl_variant(f_fwd), args.nl, g.ncols_pad, (hipStream_t)stream))) return rc;
   return launch_variant(ad_reverse_variant(f), args, g.ncols_pad, (hipStream_t)stream);
 }
 
