@@ -499,6 +499,7 @@ int nl_fair(long long ncols_pad, bool evap) {
 // fills at most half of them.
 // CLOUDSC2_PACE=0 switches it off (measurements).
 bool device_is_shared();  // cloudsc2_alloc.inc: do other ranks use this device at the same time?
+bool pace_plan(long long wgs, long long slots, int* first, int* recip_q16);
 template <class Args>
 void set_pace(Geom& g, KernelFn<Args> fn) {
   g.pace_slots = g.pace_first = g.pace_recip_q16 = 0;
@@ -526,7 +527,21 @@ void set_pace(Geom& g, KernelFn<Args> fn) {
       cache.emplace_back((const void*)fn, dev, slots);
     }
   }
-  const long long wgs = (g.ncols_pad + kBlock - 1) / kBlock, k = wgs / slots, rem = wgs % slots;
+  const long long wgs = (g.ncols_pad + kBlock - 1) / kBlock;
+  int first = 0, recip = 0;
+  if (!pace_plan(wgs, slots, &first, &recip)) return;
+  g.pace_slots = (int)slots; g.pace_first = first; g.pace_recip_q16 = recip;
+  static const bool verbose = getenv("CLOUDSC2_PACE_VERBOSE") != nullptr;
+  if (verbose)
+    fprintf(stderr, "cloudsc2: launch of %lld workgroups on %lld slots paced: %lld whole rounds + %d workgroups; the other %lld slots nap 1/%lld of every level\n",
+            wgs, slots, wgs / slots, first, slots - first, wgs / slots);
+}
+
+// The rule itself (pure arithmetic; cloudsc2_pace_plan exposes it to the tests): `wgs` workgroups on `slots` slots.
+// Returns false = not paced.
+bool pace_plan(long long wgs, long long slots, int* first, int* recip_q16) {
+  if (slots <= 0 || wgs <= 0) return false;
+  const long long k = wgs / slots, rem = wgs % slots;
   // Where it pays (profiles/r04_pacing_ab.txt, TL / AD in % of time; k whole rounds, f = the partial round's share of the slots):
   //   k 2 f 0.14: -7.7 / -6.0   k 2 f 0.44 (160 000 columns): -4.9 / -7.6   k 3 f 0.05: -7.6 / -8.0   k 5 f 0.04: -1.7 / -7.1
   //   k 6 f 0.10: -0.9 / -6.9   but k 1 f 0.53: +2.3 / +2.8   k 1 f 0.83: +1.8 / +0.5   k 2 f 0.75: +1.9 / +0.5
@@ -536,13 +551,11 @@ void set_pace(Geom& g, KernelFn<Args> fn) {
   static const long long kmin = getenv("CLOUDSC2_PACE_KMIN") ? atoll(getenv("CLOUDSC2_PACE_KMIN")) : 2;
   static const long long kmax = getenv("CLOUDSC2_PACE_KMAX") ? atoll(getenv("CLOUDSC2_PACE_KMAX")) : 8;
   static const double fmax = getenv("CLOUDSC2_PACE_FMAX") ? atof(getenv("CLOUDSC2_PACE_FMAX")) : 0.5;
-  if (k < kmin || k > kmax || rem == 0 || (double)rem > fmax * (double)slots) return;
+  if (k < kmin || k > kmax || rem == 0 || (double)rem > fmax * (double)slots) return false;
   static const double scale = getenv("CLOUDSC2_PACE_SCALE") ? atof(getenv("CLOUDSC2_PACE_SCALE")) : 1.0;  // (measurements: nap = scale / k of a level)
-  g.pace_slots = (int)slots; g.pace_first = (int)rem; g.pace_recip_q16 = (int)(scale * 65536.0 / (double)k);
-  static const bool verbose = getenv("CLOUDSC2_PACE_VERBOSE") != nullptr;
-  if (verbose)
-    fprintf(stderr, "cloudsc2: launch of %lld workgroups on %lld slots paced: %lld whole rounds + %lld workgroups; the other %lld slots nap 1/%lld of every level\n",
-            wgs, slots, k, rem, slots - rem, k);
+  *first = (int)rem;
+  *recip_q16 = (int)(scale * 65536.0 / (double)k);
+  return true;
 }
 
 // 32-bit byte offsets (C2F_OFF32) are usable when every buffer the sweep touches is smaller than 4 GiB
@@ -581,6 +594,15 @@ int cloudsc2_current_device(void) {
   return dev;
 }
 int cloudsc2_real_bytes(void) { return (int)sizeof(cloudsc2_real); }
+
+int cloudsc2_pace_plan(long long workgroups, long long slots, int* whole_rounds, int* fast_first, int* nap_recip_q16) {
+  int first = 0, recip = 0;
+  const bool on = pace_plan(workgroups, slots, &first, &recip);
+  if (whole_rounds) *whole_rounds = slots > 0 ? (int)(workgroups / slots) : 0;
+  if (fast_first) *fast_first = on ? first : 0;
+  if (nap_recip_q16) *nap_recip_q16 = on ? recip : 0;
+  return on ? 1 : 0;
+}
 
 #ifdef C2_WAVE_TIMES
 // diagnostic build only: host_buf == NULL: (re)allocate the log for `nwaves` waves and arm it; else: copy it back (4 x u64 per wave)

@@ -176,7 +176,10 @@ int cloudsc2_satur_launch(const cloudsc2_params* prm, int nproma, int nlev, int 
  * (160 000 columns on MI355X: 1250 workgroups on 512 slots), the workgroups whose slot has one workgroup less to run nap at every
  * level for 1/k of the level's measured time, leaving their share of the bandwidth to the slots on the critical path: TL -5 %, AD
  * -7 % at 160 000 columns (profiles/r04_pacing_ab.txt).  CLOUDSC2_PACE=0 in the environment switches it off,
- * CLOUDSC2_PACE_VERBOSE=1 reports paced launches on stderr. */
+ * CLOUDSC2_PACE_VERBOSE=1 reports paced launches on stderr.  cloudsc2_pace_plan is the rule itself (pure arithmetic, no device):
+ * for `workgroups` (of 128 threads) on `slots` workgroup slots it returns 1 when the launch would be paced, with the number of whole
+ * rounds, the number of leading positions of every round that form the fast class, and 65536 / k (the nap as a share of a level). */
+int cloudsc2_pace_plan(long long workgroups, long long slots, int* whole_rounds, int* fast_first, int* nap_recip_q16);
 int cloudsc2_tl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
                        const cloudsc2_inputs* traj_in, const cloudsc2_outputs* traj_out,
                        const cloudsc2_inputs* pert_in, const cloudsc2_outputs* pert_out, void* stream);

@@ -165,3 +165,24 @@ int main(void) {
                    check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
     assert out[0] == "1" and out[2] == "1" and out[3] == "0", out   # PASSED; 100 x eps is TEST OK, 1e6 x eps is not
+
+
+def test_the_pacing_rule_of_partial_rounds():
+    """cloudsc2_pace_plan (pure arithmetic behind the TL / AD launchers, include/cloudsc2_hip.h): paced = two to eight whole rounds of
+    workgroups plus a partial one that fills at most half of the slots.  MI355X at one wave per SIMD has 512 slots of 128 threads."""
+    import ctypes as C
+
+    def plan(columns, slots=512):
+        k, first, recip = C.c_int(), C.c_int(), C.c_int()
+        on = B.lib.cloudsc2_pace_plan((columns + 127) // 128, slots, C.byref(k), C.byref(first), C.byref(recip))
+        return on, k.value, first.value, recip.value
+
+    assert plan(160000) == (1, 2, 226, 32768)         # BASELINE's size: 1250 workgroups = 2 rounds + 226; nap = 1/2 of a level
+    assert plan(140000) == (1, 2, 70, 32768)
+    assert plan(200000) == (1, 3, 27, 21845)
+    assert plan(400000)[:3] == (1, 6, 53)
+    assert plan(100000)[0] == 0 and plan(100000)[1] == 1   # one whole round: measured slower with the pacing
+    assert plan(180000)[0] == 0                             # the partial round fills 75 % of the slots
+    assert plan(131072)[0] == 0                             # exactly two rounds: nothing partial
+    assert plan(1048576)[0] == 0                            # 16 rounds: nothing to gain
+    assert plan(16384)[0] == 0 and plan(160000, 0)[0] == 0
