@@ -462,7 +462,8 @@ def main():
         ds.increments(zero_supsat=(args.kernel == "ad"), into=inc)
         if args.kernel == "tl":
             step, bpc, keep = (lambda: ds.tl(prm, inc, dout, stream)), c2.bytes_per_column(nlev, "tl"), (ds, inc, dout)
-            kname = "tl_kernel<C2F_QSAT> (CLOUDSC2TL, trajectory recomputed, not stored)"
+            kname = ("tl_kernel<C2F_QSAT|C2F_TRAJ> (CLOUDSC2TL: trajectory evaluated in the sweep, its ten outputs and the ten TL outputs stored; "
+                     "launches of a few partial rounds of workgroups are paced, CLOUDSC2_PACE=0 switches that off)")
         else:
             ds.tl(prm, inc, dout, stream)  # leaves the trajectory outputs (PFPLSL5 / PFPLSN5) in the state
             # the cover-checkpoint plane exists only with the evaporation branch (its one reader)
@@ -471,8 +472,8 @@ def main():
             bpc = c2.bytes_per_column(nlev, "ad" if args.ad_sweep == "both" else "ad_reverse")
             if args.levapls2:  # + the checkpoint plane: written by the forward sweep, read by the reverse sweep
                 bpc += c2.bytes_per_column(nlev, "ad_ckpt") // (1 if args.ad_sweep == "both" else 2)
-            kname = ("ad_kernel<C2F_QSAT> (CLOUDSC2AD: trajectory pass + reverse pass)" if args.ad_sweep == "both" else
-                     "ad_reverse_kernel<C2F_QSAT> (reverse sweep of CLOUDSC2AD alone; carries from the state's PFPLSL5 / PFPLSN5)")
+            kname = ("ad_kernel<C2F_QSAT> (CLOUDSC2AD: trajectory pass + reverse pass; partial rounds paced)" if args.ad_sweep == "both" else
+                     "ad_reverse_kernel<C2F_QSAT> (reverse sweep of CLOUDSC2AD alone; carries from the state's PFPLSL5 / PFPLSN5; partial rounds paced)")
             if args.ad_assign:  # the 16 old input adjoints (15 full-level planes + PAPH's nlev+1) are not read
                 bpc -= c2.bytes_per_column(nlev, "ad_old_adjoints")
                 kname = kname.replace("<C2F_QSAT>", "<C2F_QSAT|C2F_ASSIGN>") + " [x = A^T y: old input adjoints not read]"
