@@ -595,6 +595,16 @@ int cloudsc2_current_device(void) {
 }
 int cloudsc2_real_bytes(void) { return (int)sizeof(cloudsc2_real); }
 
+int cloudsc2_simd_population(long long workgroups, int cus, long long block, int wave_in_block, int* mine, int* most) {
+  if (workgroups < 1 || cus < 1 || block < 0 || block >= workgroups || wave_in_block < 0 || wave_in_block > 1 || !mine || !most)
+    return fail(CLOUDSC2_EINVAL, "cloudsc2_simd_population: bad argument");
+  const long long q = workgroups / cus, r = workgroups % cus, c = block % cus, j = block / cus;
+  unsigned a = 0, b = 0;
+  simd_population((unsigned)(q + (c < r ? 1 : 0)), (unsigned)j, (unsigned)wave_in_block, a, b);
+  *mine = (int)a; *most = (int)b;
+  return 0;
+}
+
 int cloudsc2_pace_plan(long long workgroups, long long slots, int* whole_rounds, int* fast_first, int* nap_recip_q16) {
   int first = 0, recip = 0;
   const bool on = pace_plan(workgroups, slots, &first, &recip);
@@ -715,6 +725,19 @@ int cloudsc2_nl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
   if ((f & C2F_NOLIN) && (f & C2F_PERT))
     return fail(CLOUDSC2_EINVAL, "pert_lambda != 0 with LPHYLIN = 0: the perturbed runs of the Taylor test exist in the LPHYLIN form only");
   args.g.fair = nl_fair(g.ncols_pad, args.c.evap != 0);
+  // one-round launches: the lighter SIMDs of the fullest CUs yield (struct Pace: begin_light); CLOUDSC2_NL_LIGHT = the nap in % of a
+  // level's measured time (0 = off; 10 / 15 / 20 measured: 15 best at 160 000 columns, neutral where no CU has unequal SIMDs)
+  static const int nl_light = getenv("CLOUDSC2_NL_LIGHT") ? atoi(getenv("CLOUDSC2_NL_LIGHT")) : 15;
+  if (args.g.fair && nl_light > 0 && kBlock == 128) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) {
+      const long long wgs = (g.ncols_pad + kBlock - 1) / kBlock;
+      args.g.pace_slots = cus; args.g.pace_first = (int)(wgs / cus); args.g.pace_recip_q16 = (int)(65536.0 * nl_light / 100.0);
+      args.g.fair |= 4 | ((int)(wgs % cus) << 8);
+    } else {
+      (void)hipGetLastError();
+    }
+  }
   if (fits_off32(g, nproma, nlev, {s.full, s.half, s.cml, s.clv, s.loc, (long long)zero_plane.block_stride})) f |= C2F_OFF32;
   return launch_variant(nl_variant(f), args, g.ncols_pad, (hipStream_t)stream);
 }

@@ -180,6 +180,13 @@ int cloudsc2_satur_launch(const cloudsc2_params* prm, int nproma, int nlev, int 
  * for `workgroups` (of 128 threads) on `slots` workgroup slots it returns 1 when the launch would be paced, with the number of whole
  * rounds, the number of leading positions of every round that form the fast class, and 65536 / k (the nap as a share of a level). */
 int cloudsc2_pace_plan(long long workgroups, long long slots, int* whole_rounds, int* fast_first, int* nap_recip_q16);
+/* The NL sweep's counterpart for launches that are ONE round of waves (all resident at once; 160 000 columns on MI355X): inside the
+ * CUs that carry the most workgroups, the waves on SIMDs with fewer waves than the CU's fullest SIMD nap 15 % of every level
+ * (CLOUDSC2_NL_LIGHT=percent, 0 = off): -2 % at 160 000 columns, results unaffected.  How many waves share a SIMD follows from the
+ * block index alone; cloudsc2_simd_population is that rule (pure arithmetic, no device): for wave `wave_in_block` (0 or 1) of block
+ * `block` of a launch of `workgroups` 128-thread blocks on `cus` CUs, *mine = waves of the launch on its SIMD, *most = on the fullest
+ * SIMD of its CU.  tools/wave_times.py checks it against the hardware's own record (HW_ID) wave by wave. */
+int cloudsc2_simd_population(long long workgroups, int cus, long long block, int wave_in_block, int* mine, int* most);
 int cloudsc2_tl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
                        const cloudsc2_inputs* traj_in, const cloudsc2_outputs* traj_out,
                        const cloudsc2_inputs* pert_in, const cloudsc2_outputs* pert_out, void* stream);

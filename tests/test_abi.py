@@ -186,3 +186,23 @@ def test_the_pacing_rule_of_partial_rounds():
     assert plan(131072)[0] == 0                             # exactly two rounds: nothing partial
     assert plan(1048576)[0] == 0                            # 16 rounds: nothing to gain
     assert plan(16384)[0] == 0 and plan(160000, 0)[0] == 0
+
+
+def test_the_simd_population_rule_of_one_round_launches():
+    """cloudsc2_simd_population (pure arithmetic behind the NL launcher's light-SIMD nap): 160 000 columns = 1250 blocks on 256 CUs: 226
+    CUs carry five blocks = ten waves -- two SIMDs with three, two with two --, 30 carry four (two waves on every SIMD)."""
+    import ctypes as C
+
+    def pop(block, wave, wgs=1250, cus=256):
+        a, b = C.c_int(), C.c_int()
+        B.check(B.lib.cloudsc2_simd_population(wgs, cus, block, wave, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    for c in (0, 100, 225):  # a five-block CU: blocks c, c+256, ... c+1024; the first block's two SIMDs end up with three waves
+        got = [pop(c + 256 * j, w) for j in range(5) for w in (0, 1)]
+        assert got == [(3, 3), (3, 3), (3, 3), (2, 3), (2, 3), (2, 3), (2, 3), (3, 3), (3, 3), (3, 3)], got
+    for c in (226, 255):     # a four-block CU: all equal
+        assert all(pop(c + 256 * j, w) == (2, 2) for j in range(4) for w in (0, 1))
+    heavy = sum(pop(b, w)[0] == 3 for b in range(1250) for w in (0, 1))
+    assert heavy == 1356  # = 452 SIMDs x 3 waves (profiles/r03_wave_times.txt)
+    assert B.lib.cloudsc2_simd_population(1250, 256, 1250, 0, C.byref(C.c_int()), C.byref(C.c_int())) != 0

@@ -898,8 +898,9 @@ def test_test_drivers_against_the_reference_drivers_run_here(nproma, ngptot):
 def test_pacing_of_partial_rounds_changes_no_bits():
     """TL / AD launches of a few partial rounds of workgroups are paced (cloudsc2_column.hpp: struct Pace -- workgroups whose slot has
     one workgroup less to run nap at every level; 140 000 columns = 1094 workgroups on 512 slots: 2 rounds + 70): a matter of WHEN
-    waves run, never of what they compute.  Fresh processes with the pacing on (default) and off give identical bits for every TL
-    output and every input adjoint; the launcher reports the pacing for this size and not for 16 384 columns."""
+    waves run, never of what they compute -- like the nap of the lighter SIMDs in a one-round NL launch.  Fresh processes with both on
+    (default) and off give identical bits for every NL output, every TL output and every input adjoint; the launcher reports the
+    pacing for this size and not for 16 384 columns."""
     import subprocess
     import sys
 
@@ -910,10 +911,12 @@ def test_pacing_of_partial_rounds_changes_no_bits():
         "import torch, dwarf_p_cloudsc2_tl_ad_amd as c2\n"
         "tab = c2.synthetic_table(); prm = c2.default_params(c2.ceta_from_table(tab), lregcl=True)\n"
         "for n in (16384, 140000):\n"
-        "    ds = c2.DeviceState.from_table(tab, 128, n); ds.satur(prm)\n"
+        "    ds = c2.DeviceState.from_table(tab, 128, n); h = hashlib.sha256()\n"
+        "    ds.nl(prm); torch.cuda.synchronize()\n"   # (one round of waves at both sizes: the lighter SIMDs of the fullest CUs nap)
+        "    for t in (ds.B_LOC, ds.PA, ds.PCOVPTOT, ds.PFPLSL, ds.PFPLSN, ds.PFHPSL, ds.PFHPSN): h.update(t.cpu().numpy().tobytes())\n"
+        "    ds.satur(prm)\n"
         "    dx = ds.increments(zero_supsat=True); dy = c2.FlatFields('out', ds.nb, ds.nlev, ds.nproma, ds.device)\n"
         "    ds.tl(prm, dx, dy); torch.cuda.synchronize()\n"
-        "    h = hashlib.sha256()\n"
         "    for k in sorted(dy.t): h.update(dy.t[k].cpu().numpy().tobytes())\n"
         "    xa = c2.FlatFields('in', ds.nb, ds.nlev, ds.nproma, ds.device)\n"
         "    ds.ad(prm, xa, dy, ds.new_scratch()); torch.cuda.synchronize()\n"
@@ -921,13 +924,13 @@ def test_pacing_of_partial_rounds_changes_no_bits():
         "    print('HASH', n, h.hexdigest())\n" % ROOT)
 
     def run(env):
-        e = {k: v for k, v in os.environ.items() if not k.startswith("CLOUDSC2_PACE")}
+        e = {k: v for k, v in os.environ.items() if not k.startswith(("CLOUDSC2_PACE", "CLOUDSC2_NL_LIGHT"))}
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env={**e, **env})
         assert r.returncode == 0, r.stderr[-3000:]
         return [ln for ln in r.stdout.splitlines() if ln.startswith("HASH")], r.stderr
 
     on, err_on = run({"CLOUDSC2_PACE_VERBOSE": "1"})
-    off, err_off = run({"CLOUDSC2_PACE": "0", "CLOUDSC2_PACE_VERBOSE": "1"})
+    off, err_off = run({"CLOUDSC2_PACE": "0", "CLOUDSC2_NL_LIGHT": "0", "CLOUDSC2_PACE_VERBOSE": "1"})
     assert len(on) == 2 and on == off, (on, off)
     assert "launch of 1094 workgroups on 512 slots paced: 2 whole rounds + 70 workgroups" in err_on, err_on[-1500:]
     assert "launch of 128 workgroups" not in err_on and "paced" not in err_off

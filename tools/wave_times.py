@@ -80,6 +80,16 @@ for rep in range(5):
                 "slow_class_waves_by_waves_on_their_simd": {int(k): int(((share == k) & ~fast).sum()) for k in np.unique(share)},
                 "end_us_fast_class_p50_p100": [round(float(np.median(end[fast])), 1), round(float(end[fast].max()), 1)] if fast.any() else None,
                 "end_us_slow_class_p50_p100": [round(float(np.median(end[~fast])), 1), round(float(end[~fast].max()), 1)] if (~fast).any() else None}
+    if kind == "nl":  # the population rule behind the light-SIMD nap (cloudsc2_simd_population) against where the waves really ran
+        idx = np.nonzero(ok)[0]
+        cus = torch.cuda.get_device_properties(0).multi_processor_count
+        a_, b_ = C.c_int(), C.c_int()
+        pred = np.zeros(len(idx), dtype=np.int64)
+        for n_, w_ in enumerate(idx):
+            B.check(B.lib.cloudsc2_simd_population(nwaves // 2, cus, int(w_) // 2, int(w_) & 1, C.byref(a_), C.byref(b_)))
+            pred[n_] = a_.value
+        pace = {"rule": "cloudsc2_simd_population", "waves": int(len(idx)), "predicted_population_equals_waves_on_the_simd": int((pred == share).sum()),
+                "end_us_median_by_waves_on_the_simd": {int(k): round(float(np.median(end[share == k])), 1) for k in np.unique(share)}}
     r = {"event_ms": ev0.elapsed_time(ev1), "kernel": kind, "pace_rule_vs_reality": pace,
          "nth_wave_of_its_simd_start_end_duration_us_median": {k: [round(float(np.median([x[j] for x in v])), 1) for j in range(3)] + [len(v)] for k, v in sorted(nth.items()) if k < 8}, "waves": int(ok.sum()), "simds_used": int(len(uniq)),
          "start_us_p0_10_50_90_99_100": q(start), "end_us": q(end), "duration_us": q(dur),
