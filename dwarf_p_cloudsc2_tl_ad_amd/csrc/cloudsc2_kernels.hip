@@ -494,6 +494,64 @@ int nl_fair(long long ncols_pad, bool evap) {
   return waves <= slots;
 }
 
+// Does THIS device place the waves of a one-round launch the way simd_population (cloudsc2_column.hpp) says?  Checked once per device and
+// process, before the rule is used for the first time: a launch of the NL kernel's shape (128-thread workgroups, all resident at
+// once; five workgroups on most CUs, four on the rest) whose waves record where they run (HW_ID / XCC_ID) and stay for ~30 us so
+// that nothing is placed into a freed slot.  Any wave whose SIMD carries another number of waves than predicted -- another
+// dispatcher, other work on the device during the probe -- and the lighter SIMDs' nap stays off for this device (the sweep is
+// then as it was before round 4).  Costs one 40 us kernel and a 10 KB copy per process.
+__global__ void __launch_bounds__(kBlock) dispatch_probe_kernel(unsigned long long* out) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    out[((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6] = ((unsigned long long)xcc << 32) | hw;
+  }
+  for (int i = 0; i < 8; ++i) __builtin_amdgcn_s_sleep(127);  // ~65 000 clocks: every workgroup of the probe is dispatched meanwhile
+#endif
+}
+struct DispatchRule { int device; bool holds; };
+std::mutex g_rule_mutex;
+std::vector<DispatchRule> g_rules;
+int probe_dispatch(int cus, long long* checked, long long* wrong) {
+  const long long wgs = 5LL * cus - cus / 8 - 2, nwaves = 2 * wgs;  // five workgroups on most CUs, four on the rest (1250 on 256 CUs)
+  unsigned long long* dev = nullptr;
+  HIP_TRY(hipMalloc((void**)&dev, (size_t)nwaves * sizeof(unsigned long long)));
+  std::vector<unsigned long long> rec((size_t)nwaves, 0ull);
+  hipLaunchKernelGGL(dispatch_probe_kernel, dim3((unsigned)wgs), dim3(kBlock), 0, nullptr, dev);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpy(rec.data(), dev, (size_t)nwaves * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  (void)hipFree(dev);
+  if (e != hipSuccess) { g_err = std::string("dispatch probe: ") + hipGetErrorString(e); return (int)e; }
+  // waves of the launch per SIMD, from the hardware's record: XCC_ID[3:0] | HW_ID: se [15:13], sh [12], cu [11:8], simd [5:4]
+  std::vector<unsigned long long> key((size_t)nwaves);
+  for (long long w = 0; w < nwaves; ++w) key[w] = ((rec[w] >> 32) & 0xfull) << 16 | (rec[w] & 0xff30ull);
+  std::vector<unsigned long long> sorted(key);
+  std::sort(sorted.begin(), sorted.end());
+  *checked = nwaves; *wrong = 0;
+  const long long q = wgs / cus, r = wgs % cus;
+  for (long long w = 0; w < nwaves; ++w) {
+    const long long i = w / 2, c = i % cus, j = i / cus;
+    unsigned mine = 0, most = 0;
+    simd_population((unsigned)(q + (c < r ? 1 : 0)), (unsigned)j, (unsigned)(w & 1), mine, most);
+    const auto range = std::equal_range(sorted.begin(), sorted.end(), key[w]);
+    if ((long long)(range.second - range.first) != (long long)mine) ++*wrong;
+  }
+  return 0;
+}
+// true = the rule was checked on the calling thread's current device and held for every wave
+bool dispatch_rule_holds(int device, int cus) {
+  std::lock_guard<std::mutex> lock(g_rule_mutex);
+  for (auto& e : g_rules)
+    if (e.device == device) return e.holds;
+  long long checked = 0, wrong = 0;
+  const bool ok = probe_dispatch(cus, &checked, &wrong) == 0 && wrong == 0;
+  if (getenv("CLOUDSC2_PACE_VERBOSE"))
+    fprintf(stderr, "cloudsc2: dispatch probe on device %d: %lld of %lld waves sit on a SIMD with the predicted number of waves -> the lighter SIMDs' nap is %s\n",
+            device, checked - wrong, checked, ok ? "on" : "off");
+  g_rules.push_back(DispatchRule{device, ok});
+  return ok;
+}
+
 // Pacing of a TL / AD launch (cloudsc2_column.hpp: struct Pace): on when the launch is two to eight whole rounds of workgroups on the
 // slots the device has for THIS kernel (its occupancy, asked of the runtime once per kernel and device) plus a partial round that
 // fills at most half of them.
@@ -603,6 +661,15 @@ int cloudsc2_simd_population(long long workgroups, int cus, long long block, int
   simd_population((unsigned)(q + (c < r ? 1 : 0)), (unsigned)j, (unsigned)wave_in_block, a, b);
   *mine = (int)a; *most = (int)b;
   return 0;
+}
+
+int cloudsc2_dispatch_probe(long long* waves_checked, long long* waves_wrong) {
+  if (!waves_checked || !waves_wrong) return fail(CLOUDSC2_EINVAL, "cloudsc2_dispatch_probe: NULL argument");
+  if (!device_ok()) return fail(CLOUDSC2_ENODEVICE, "no HIP device available (this library has no CPU path)");
+  int dev = 0, cus = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  return probe_dispatch(cus, waves_checked, waves_wrong);
 }
 
 int cloudsc2_pace_plan(long long workgroups, long long slots, int* whole_rounds, int* fast_first, int* nap_recip_q16) {
@@ -730,7 +797,8 @@ int cloudsc2_nl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
   static const int nl_light = getenv("CLOUDSC2_NL_LIGHT") ? atoi(getenv("CLOUDSC2_NL_LIGHT")) : 15;
   if (args.g.fair && nl_light > 0 && kBlock == 128) {
     int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) {
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0 &&
+        !device_is_shared() && dispatch_rule_holds(dev, cus)) {
       const long long wgs = (g.ncols_pad + kBlock - 1) / kBlock;
       args.g.pace_slots = cus; args.g.pace_first = (int)(wgs / cus); args.g.pace_recip_q16 = (int)(65536.0 * nl_light / 100.0);
       args.g.fair |= 4 | ((int)(wgs % cus) << 8);

@@ -187,6 +187,11 @@ int cloudsc2_pace_plan(long long workgroups, long long slots, int* whole_rounds,
  * `block` of a launch of `workgroups` 128-thread blocks on `cus` CUs, *mine = waves of the launch on its SIMD, *most = on the fullest
  * SIMD of its CU.  tools/wave_times.py checks it against the hardware's own record (HW_ID) wave by wave. */
 int cloudsc2_simd_population(long long workgroups, int cus, long long block, int wave_in_block, int* mine, int* most);
+/* The library does not take that rule on trust: before it is used for the first time on a device (once per process) a 40 us probe
+ * launch of the NL kernel's shape records where its waves run (HW_ID) and the rule is checked wave by wave; one miss -- another
+ * dispatcher, other work on the device at that moment -- and the nap stays off for the device.  cloudsc2_dispatch_probe runs the
+ * same probe on the current device and returns the counts (GPU tests; CLOUDSC2_PACE_VERBOSE=1 prints the library's own verdict). */
+int cloudsc2_dispatch_probe(long long* waves_checked, long long* waves_wrong);
 int cloudsc2_tl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
                        const cloudsc2_inputs* traj_in, const cloudsc2_outputs* traj_out,
                        const cloudsc2_inputs* pert_in, const cloudsc2_outputs* pert_out, void* stream);

@@ -934,3 +934,19 @@ def test_pacing_of_partial_rounds_changes_no_bits():
     assert len(on) == 2 and on == off, (on, off)
     assert "launch of 1094 workgroups on 512 slots paced: 2 whole rounds + 70 workgroups" in err_on, err_on[-1500:]
     assert "launch of 128 workgroups" not in err_on and "paced" not in err_off
+
+
+def test_the_dispatch_rule_holds_on_this_device():
+    """The nap of the lighter SIMDs in one-round NL launches rests on a rule about where the dispatcher puts the waves of a launch
+    (cloudsc2_simd_population).  The library checks it on the device before using it (a 40 us probe launch whose waves record their
+    HW_ID; one miss and the nap stays off); the same probe through the ABI: every wave sits on a SIMD with the predicted number of waves."""
+    import ctypes as C
+
+    import torch
+
+    torch.cuda.synchronize()  # (an idle device: other work would be placed between the probe's waves)
+    for _ in range(3):
+        checked, wrong = C.c_longlong(), C.c_longlong()
+        B.check(B.lib.cloudsc2_dispatch_probe(C.byref(checked), C.byref(wrong)))
+        cus = torch.cuda.get_device_properties(0).multi_processor_count
+        assert checked.value == 2 * (5 * cus - cus // 8 - 2) and wrong.value == 0, (checked.value, wrong.value)
