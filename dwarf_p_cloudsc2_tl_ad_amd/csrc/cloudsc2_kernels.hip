@@ -502,6 +502,8 @@ int nl_fair(long long ncols_pad, bool evap) {
 // then as it was before round 4).  Costs one 40 us kernel and a 10 KB copy per process.
 __global__ void __launch_bounds__(kBlock) dispatch_probe_kernel(unsigned long long* out) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ unsigned probe_lds[];
+  if (threadIdx.x == 0) probe_lds[0] = blockIdx.x;  // (the allocation must not be optimised away)
   if ((threadIdx.x & 63) == 0) {
     const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
     out[((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6] = ((unsigned long long)xcc << 32) | hw;
@@ -517,7 +519,12 @@ int probe_dispatch(int cus, long long* checked, long long* wrong) {
   unsigned long long* dev = nullptr;
   HIP_TRY(hipMalloc((void**)&dev, (size_t)nwaves * sizeof(unsigned long long)));
   std::vector<unsigned long long> rec((size_t)nwaves, 0ull);
-  hipLaunchKernelGGL(dispatch_probe_kernel, dim3((unsigned)wgs), dim3(kBlock), 0, nullptr, dev);
+  // (26 KiB of dynamic LDS per workgroup: six workgroups = three waves per SIMD fit a CU, the NL kernel's own occupancy -- a probe
+  //  that could pile more waves on a SIMD is placed differently)
+  // twice: the first launch of a kernel in a process loads its code object while its first workgroups already run and leave -- its
+  // placement says nothing (measured: 384 of 2492 waves off on the first launch, 0 on every later one)
+  for (int rep = 0; rep < 2; ++rep)
+    hipLaunchKernelGGL(dispatch_probe_kernel, dim3((unsigned)wgs), dim3(kBlock), 26 * 1024, nullptr, dev);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpy(rec.data(), dev, (size_t)nwaves * sizeof(unsigned long long), hipMemcpyDeviceToHost);
   (void)hipFree(dev);
