@@ -546,10 +546,15 @@ int probe_dispatch(int cus, long long* checked, long long* wrong) {
   return 0;
 }
 // true = the rule was checked on the calling thread's current device and held for every wave
-bool dispatch_rule_holds(int device, int cus) {
+bool dispatch_rule_holds(int device, int cus, hipStream_t launch_stream) {
   std::lock_guard<std::mutex> lock(g_rule_mutex);
   for (auto& e : g_rules)
     if (e.device == device) return e.holds;
+  // the probe allocates, launches on the null stream and copies back: not inside a stream capture (this launch then goes without the
+  // nap, and the question stays open for the next one)
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(launch_stream, &cap) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (cap != hipStreamCaptureStatusNone) return false;
   long long checked = 0, wrong = 0;
   const bool ok = probe_dispatch(cus, &checked, &wrong) == 0 && wrong == 0;
   if (getenv("CLOUDSC2_PACE_VERBOSE"))
@@ -805,7 +810,7 @@ int cloudsc2_nl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
   if (args.g.fair && nl_light > 0 && kBlock == 128) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0 &&
-        !device_is_shared() && dispatch_rule_holds(dev, cus)) {
+        !device_is_shared() && dispatch_rule_holds(dev, cus, (hipStream_t)stream)) {
       const long long wgs = (g.ncols_pad + kBlock - 1) / kBlock;
       args.g.pace_slots = cus; args.g.pace_first = (int)(wgs / cus); args.g.pace_recip_q16 = (int)(65536.0 * nl_light / 100.0);
       args.g.fair |= 4 | ((int)(wgs % cus) << 8);
