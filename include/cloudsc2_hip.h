@@ -159,7 +159,11 @@ typedef struct cloudsc2_outputs {
  * i.e. TENDENCY_LOC(IBL)%cld(:,:,NCLV)=0 of cloudsc_driver_mod.F90:88.
  * pert_lambda != 0: every input x is replaced on load by x + pert_lambda*(0.01*x), the perturbed state
  * of the Taylor test (cloudsc_driver_tl_mod.F90:156-171,200-215); with fused SATUR, PQS is perturbed the
- * same way after SATUR on the unperturbed PAP,PT (:159,:203). */
+ * same way after SATUR on the unperturbed PAP,PT (:159,:203).
+ * Asynchronous on `stream` -- with one exception per process and device: the first launch that is ONE round of waves (<= 196 608
+ * columns on MI355X) first runs the 40 us dispatch probe described at cloudsc2_dispatch_probe below (a small allocation, a launch on
+ * the NULL stream and a copy back: it synchronises with the null stream once); not while `stream` is capturing, and not with
+ * CLOUDSC2_NL_LIGHT=0. */
 int cloudsc2_nl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
                        const cloudsc2_inputs* in, const cloudsc2_outputs* out, cloudsc2_field zero_plane,
                        double pert_lambda, void* stream);
