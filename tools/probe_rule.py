@@ -1,5 +1,10 @@
-import sys, ctypes as C
-sys.path.insert(0, '/root/repo')
+"""usage: python tools/probe_rule.py  -- on a GPU box: cloudsc2_dispatch_probe six times before and three times after an NL launch
+(waves checked / waves off the predicted SIMD population)."""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import dwarf_p_cloudsc2_tl_ad_amd as c2
 from dwarf_p_cloudsc2_tl_ad_amd import binding as B
