@@ -180,6 +180,14 @@ def _load() -> C.CDLL:
     lib.cloudsc2_simd_population.restype = C.c_int
     lib.cloudsc2_dispatch_probe.argtypes = [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     lib.cloudsc2_dispatch_probe.restype = C.c_int
+    lib.cloudsc2_pace_probe.argtypes = [C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+    lib.cloudsc2_pace_probe.restype = C.c_int
+    lib.cloudsc2_device_prepare.argtypes = []
+    lib.cloudsc2_device_prepare.restype = C.c_int
+    lib.cloudsc2_device_rules.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.cloudsc2_device_rules.restype = C.c_int
+    lib.cloudsc2_kernel_occupancy.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int)]
+    lib.cloudsc2_kernel_occupancy.restype = C.c_int
     lib.cloudsc2_device_probe.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, dp]
     lib.cloudsc2_device_probe.restype = C.c_int
     lib.cloudsc2_device_malloc_state.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_int, C.c_int, C.c_int]
@@ -217,7 +225,7 @@ EXPORTED = ("cloudsc2_params_default", "cloudsc2_last_error", "cloudsc2_device_a
             "cloudsc2_release_workspace", "cloudsc2_taylor_verdict", "cloudsc2_adjoint_verdict",
             "cloudsc2_expand_launch", "cloudsc2_validate_workspace_doubles", "cloudsc2_validate_launch",
             "cloudsc2_expand_offsets", "cloudsc2_validate_relerr", "cloudsc2_validate_format", "cloudsc2_validate_header",
-            "cloudsc2_device_malloc", "cloudsc2_device_free", "cloudsc2_device_malloc_info", "cloudsc2_device_malloc_counts", "cloudsc2_pace_plan", "cloudsc2_simd_population", "cloudsc2_dispatch_probe", "cloudsc2_device_probe", "cloudsc2_device_malloc_state",
+            "cloudsc2_device_malloc", "cloudsc2_device_free", "cloudsc2_device_malloc_info", "cloudsc2_device_malloc_counts", "cloudsc2_pace_plan", "cloudsc2_simd_population", "cloudsc2_dispatch_probe", "cloudsc2_pace_probe", "cloudsc2_device_prepare", "cloudsc2_device_rules", "cloudsc2_kernel_occupancy", "cloudsc2_device_probe", "cloudsc2_device_malloc_state",
             "cloudsc2_state_create", "cloudsc2_state_destroy", "cloudsc2_state_field", "cloudsc2_state_blocking", "cloudsc2_state_expand",
             "cloudsc2_state_upload", "cloudsc2_state_download", "cloudsc2_state_nl", "cloudsc2_state_tl_taylor",
             "cloudsc2_state_ad_symmetry", "cloudsc2_state_validate")

@@ -131,8 +131,27 @@ int get_tables(const cloudsc2_params& p, const LevelTab** dev, int* kb0, int* kb
     }
   }
   if (e.kb1 <= e.kb0) { e.kb0 = 0; e.kb1 = 0; }
-  HIP_TRY(hipMalloc((void**)&e.dev, sizeof(LevelTab)));
-  HIP_TRY(hipMemcpy(e.dev, &host, sizeof(LevelTab), hipMemcpyHostToDevice));
+  // (a launcher may be the first to ask for this table, possibly while ANOTHER stream of the process is being captured into a graph:
+  //  the thread's capture mode is relaxed for the allocation, and the upload goes through a private non-blocking stream instead of
+  //  the legacy stream, which would synchronise with -- and invalidate -- such a capture.  A launch on a stream that is itself
+  //  capturing needs its table to exist already: any earlier launch, cloudsc2_state_* call or driver call with the same CETA made it.)
+  {
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    const bool exchanged = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess;
+    hipStream_t up = nullptr;
+    hipError_t err = hipStreamCreateWithFlags(&up, hipStreamNonBlocking);
+    if (err == hipSuccess) err = hipMalloc((void**)&e.dev, sizeof(LevelTab));
+    if (err == hipSuccess) err = hipMemcpyAsync(e.dev, &host, sizeof(LevelTab), hipMemcpyHostToDevice, up);
+    if (err == hipSuccess) err = hipStreamSynchronize(up);
+    if (up) (void)hipStreamDestroy(up);
+    if (exchanged) (void)hipThreadExchangeStreamCaptureMode(&mode);
+    if (err != hipSuccess) {
+      if (e.dev) (void)hipFree(e.dev);
+      (void)hipGetLastError();
+      g_err = std::string("level tables: ") + hipGetErrorString(err);
+      return (int)err;
+    }
+  }
   g_tabs.push_back(e);
   *dev = e.dev; *kb0 = e.kb0; *kb1 = e.kb1;
   return 0;
@@ -494,12 +513,28 @@ int nl_fair(long long ncols_pad, bool evap) {
   return waves <= slots;
 }
 
-// Does THIS device place the waves of a one-round launch the way simd_population (cloudsc2_column.hpp) says?  Checked once per device and
-// process, before the rule is used for the first time: a launch of the NL kernel's shape (128-thread workgroups, all resident at
-// once; five workgroups on most CUs, four on the rest) whose waves record where they run (HW_ID / XCC_ID) and stay for ~30 us so
-// that nothing is placed into a freed slot.  Any wave whose SIMD carries another number of waves than predicted -- another
-// dispatcher, other work on the device during the probe -- and the lighter SIMDs' nap stays off for this device (the sweep is
-// then as it was before round 4).  Costs one 40 us kernel and a 10 KB copy per process.
+// ---------------------------------------------------------------------------------------------------------
+// What the two launch heuristics take for granted about the device's dispatcher, checked on the device -- at a SYNCHRONOUS moment
+// (cloudsc2_device_prepare: called by every allocating entry point of the library and by the host-array drivers, or by the caller
+// itself), never from a launch: the launchers only read the cached verdicts, and a device nobody prepared runs without the naps.
+//
+// (1) NL, one round of waves: does the device place the waves the way simd_population (cloudsc2_column.hpp) says?  A launch of the NL
+//     kernel's shape (128-thread workgroups, all resident at once; five workgroups on most CUs, four on the rest) whose waves record
+//     where they run (HW_ID / XCC_ID) and stay for ~30 us so that nothing is placed into a freed slot.  Any wave whose SIMD carries
+//     another number of waves than predicted -- another dispatcher, other work on the device during the probe -- and the lighter
+//     SIMDs' nap stays off for this device.
+// (2) TL / AD, a few rounds of workgroups at `per_cu` workgroups per CU: Pace::begin decides from blockIdx mod slots alone which
+//     workgroups sit on a slot that has one workgroup more to run.  That holds when (a) the first `slots` workgroups are all
+//     resident at once, one per slot, and (b) a freed slot receives the next workgroup in index order.  The probe is a launch of
+//     that shape (2 rounds + 0.44 of one; `per_cu` workgroups per CU enforced through LDS) whose workgroups do nothing but stay
+//     for the time their class would -- 40 us the fast class (blockIdx mod slots < rem), 60 us the napping class (k = 2: 1 + 1/k) --
+//     and record where they ran and when they started.  Checked per CU: it must have run (k+1) workgroups of the fast class for
+//     each fast workgroup it received in the first round and k of the slow class for each slow one, and every first-round
+//     workgroup must have started before the first one left.  One miss and TL / AD launches on this device are not paced.
+// Each probe costs an 8-40 KB allocation, two launches on a private non-blocking stream and a copy back; the thread's capture mode
+// is relaxed meanwhile, so that a graph capture going on elsewhere in the process is not invalidated.  A probe that ends in a HIP
+// error leaves NO verdict (the next prepare tries again).
+// ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) dispatch_probe_kernel(unsigned long long* out) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ unsigned probe_lds[];
@@ -511,23 +546,62 @@ __global__ void __launch_bounds__(kBlock) dispatch_probe_kernel(unsigned long lo
   for (int i = 0; i < 8; ++i) __builtin_amdgcn_s_sleep(127);  // ~65 000 clocks: every workgroup of the probe is dispatched meanwhile
 #endif
 }
-struct DispatchRule { int device; bool holds; };
-std::mutex g_rule_mutex;
-std::vector<DispatchRule> g_rules;
+// out[2*b] = start (100 MHz constant clock), out[2*b+1] = XCC_ID << 32 | HW_ID of workgroup b's first wave
+[[maybe_unused]] constexpr unsigned kPaceProbeFastTicks = 4000u, kPaceProbeSlowTicks = 6000u;  // 40 us / 60 us: k = 2 whole rounds, nap = 1/k
+__global__ void __launch_bounds__(kBlock) pace_probe_kernel(unsigned long long* out, unsigned slots, unsigned first) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ unsigned probe_lds[];
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) {
+    probe_lds[0] = blockIdx.x;
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    out[2ull * blockIdx.x] = t0;
+    out[2ull * blockIdx.x + 1] = ((unsigned long long)xcc << 32) | hw;
+  }
+  const unsigned stay = (blockIdx.x % slots) < first ? kPaceProbeFastTicks : kPaceProbeSlowTicks;
+  for (int i = 0; i < 4096 && __builtin_amdgcn_s_memrealtime() - t0 < stay; ++i) __builtin_amdgcn_s_sleep(16);  // (bounded: every wave leaves)
+#endif
+}
+
+// a probe's surroundings: relaxed capture mode for this thread, a private non-blocking stream, a device buffer
+struct ProbeScope {
+  hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+  bool exchanged = false;
+  hipStream_t stream = nullptr;
+  unsigned long long* dev = nullptr;
+  hipError_t open(size_t bytes) {
+    if (hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess) exchanged = true; else (void)hipGetLastError();
+    hipError_t e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void**)&dev, bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(dev, 0, bytes, stream);
+    return e;
+  }
+  hipError_t fetch(void* host, size_t bytes) {
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    return e;
+  }
+  ~ProbeScope() {
+    if (dev) (void)hipFree(dev);
+    if (stream) (void)hipStreamDestroy(stream);
+    if (exchanged) (void)hipThreadExchangeStreamCaptureMode(&mode);
+    (void)hipGetLastError();
+  }
+};
+
 int probe_dispatch(int cus, long long* checked, long long* wrong) {
   const long long wgs = 5LL * cus - cus / 8 - 2, nwaves = 2 * wgs;  // five workgroups on most CUs, four on the rest (1250 on 256 CUs)
-  unsigned long long* dev = nullptr;
-  HIP_TRY(hipMalloc((void**)&dev, (size_t)nwaves * sizeof(unsigned long long)));
   std::vector<unsigned long long> rec((size_t)nwaves, 0ull);
+  ProbeScope ps;
+  hipError_t e = ps.open((size_t)nwaves * sizeof(unsigned long long));
   // (26 KiB of dynamic LDS per workgroup: six workgroups = three waves per SIMD fit a CU, the NL kernel's own occupancy -- a probe
   //  that could pile more waves on a SIMD is placed differently)
   // twice: the first launch of a kernel in a process loads its code object while its first workgroups already run and leave -- its
   // placement says nothing (measured: 384 of 2492 waves off on the first launch, 0 on every later one)
-  for (int rep = 0; rep < 2; ++rep)
-    hipLaunchKernelGGL(dispatch_probe_kernel, dim3((unsigned)wgs), dim3(kBlock), 26 * 1024, nullptr, dev);
-  hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipMemcpy(rec.data(), dev, (size_t)nwaves * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-  (void)hipFree(dev);
+  for (int rep = 0; rep < 2 && e == hipSuccess; ++rep)
+    hipLaunchKernelGGL(dispatch_probe_kernel, dim3((unsigned)wgs), dim3(kBlock), 26 * 1024, ps.stream, ps.dev);
+  if (e == hipSuccess) e = ps.fetch(rec.data(), (size_t)nwaves * sizeof(unsigned long long));
   if (e != hipSuccess) { g_err = std::string("dispatch probe: ") + hipGetErrorString(e); return (int)e; }
   // waves of the launch per SIMD, from the hardware's record: XCC_ID[3:0] | HW_ID: se [15:13], sh [12], cu [11:8], simd [5:4]
   std::vector<unsigned long long> key((size_t)nwaves);
@@ -545,30 +619,166 @@ int probe_dispatch(int cus, long long* checked, long long* wrong) {
   }
   return 0;
 }
-// true = the rule was checked on the calling thread's current device and held for every wave
-bool dispatch_rule_holds(int device, int cus, hipStream_t launch_stream) {
+
+// LDS per workgroup that lets exactly `per_cu` workgroups of the probe share a CU (asked of the runtime, not assumed); 0 = none found
+size_t pace_probe_lds(int per_cu) {
+  if (per_cu < 1 || per_cu > 8) return 0;
+  const size_t cands[] = {(size_t)(160 * 1024) / (size_t)per_cu, (size_t)(128 * 1024) / (size_t)per_cu, (size_t)(64 * 1024) / (size_t)per_cu};
+  for (size_t lds : cands) {
+    lds &= ~(size_t)1023;
+    if (lds == 0) continue;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)pace_probe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      (void)hipGetLastError();
+      continue;
+    }
+    int got = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&got, (const void*)pace_probe_kernel, kBlock, lds) != hipSuccess) { (void)hipGetLastError(); continue; }
+    if (got == per_cu) return lds;
+  }
+  return 0;
+}
+
+// *checked = workgroups of the probe launch, *wrong = workgroups off the rule (or that started late); returns 0, a hipError_t, or
+// CLOUDSC2_EINVAL when no probe of that shape can be built (then there is no verdict and no pacing)
+int probe_pace(int cus, int per_cu, long long* checked, long long* wrong) {
+  const size_t lds = pace_probe_lds(per_cu);
+  if (!lds) return fail(CLOUDSC2_EINVAL, "pace probe: no LDS size gives the probe this many workgroups per CU");
+  const long long slots = (long long)cus * per_cu, k = 2, rem = slots * 113 / 256, wgs = k * slots + rem;  // 512 slots: 1250 workgroups, 226 fast
+  if (rem < 1) return fail(CLOUDSC2_EINVAL, "pace probe: device too small");
+  std::vector<unsigned long long> rec((size_t)(2 * wgs), 0ull);
+  ProbeScope ps;
+  hipError_t e = ps.open(rec.size() * sizeof(unsigned long long));
+  for (int rep = 0; rep < 2 && e == hipSuccess; ++rep)  // (twice: see probe_dispatch)
+    hipLaunchKernelGGL(pace_probe_kernel, dim3((unsigned)wgs), dim3(kBlock), lds, ps.stream, ps.dev, (unsigned)slots, (unsigned)rem);
+  if (e == hipSuccess) e = ps.fetch(rec.data(), rec.size() * sizeof(unsigned long long));
+  if (e != hipSuccess) { g_err = std::string("pace probe: ") + hipGetErrorString(e); return (int)e; }
+  *checked = wgs; *wrong = 0;
+  // (a) the whole first round resident at once: started before the first workgroup can have left
+  unsigned long long t_min = ~0ull;
+  for (long long b = 0; b < wgs; ++b) t_min = std::min(t_min, rec[2 * b]);
+  for (long long b = 0; b < slots; ++b)
+    if (rec[2 * b] - t_min >= kPaceProbeFastTicks / 2) ++*wrong;
+  // (b) per CU (XCC_ID[3:0] | HW_ID se [15:13], sh [12], cu [11:8]): the classes it received in the first round decide what it runs later
+  struct CuCount { long long fast1 = 0, slow1 = 0, fast = 0, slow = 0; };
+  std::vector<std::pair<unsigned long long, CuCount>> cu_tab;
+  auto at = [&](unsigned long long key) -> CuCount& {
+    for (auto& c : cu_tab) if (c.first == key) return c.second;
+    cu_tab.emplace_back(key, CuCount());
+    return cu_tab.back().second;
+  };
+  for (long long b = 0; b < wgs; ++b) {
+    const unsigned long long key = ((rec[2 * b + 1] >> 32) & 0xfull) << 16 | (rec[2 * b + 1] & 0xff00ull);
+    CuCount& c = at(key);
+    const bool fast = (b % slots) < rem;
+    (fast ? c.fast : c.slow) += 1;
+    if (b < slots) (fast ? c.fast1 : c.slow1) += 1;
+  }
+  if ((long long)cu_tab.size() != cus) *wrong += std::llabs((long long)cu_tab.size() - cus) * per_cu;
+  for (auto& c : cu_tab) {
+    if (c.second.fast1 + c.second.slow1 != per_cu) *wrong += std::llabs(c.second.fast1 + c.second.slow1 - per_cu);
+    *wrong += std::llabs(c.second.fast - (k + 1) * c.second.fast1) + std::llabs(c.second.slow - k * c.second.slow1);
+  }
+  return 0;
+}
+
+// cached verdicts: 1 = holds, 0 = does not; absent = never probed (or the probe itself failed)
+struct DeviceRules {
+  int device;
+  int nl_rule = -1;
+  std::vector<std::pair<int, int>> pace;  // (workgroups per CU, verdict)
+  int pace_of(int per_cu) const {
+    for (auto& p : pace) if (p.first == per_cu) return p.second;
+    return -1;
+  }
+};
+std::mutex g_rule_mutex;
+std::vector<DeviceRules> g_rules;
+bool pace_verbose() { static const bool v = getenv("CLOUDSC2_PACE_VERBOSE") != nullptr; return v; }
+
+// read-only, for the launchers: nothing here touches the device
+int cached_nl_rule(int device) {
+  std::lock_guard<std::mutex> lock(g_rule_mutex);
+  for (auto& e : g_rules) if (e.device == device) return e.nl_rule;
+  return -1;
+}
+int cached_pace_rule(int device, int per_cu) {
+  std::lock_guard<std::mutex> lock(g_rule_mutex);
+  for (auto& e : g_rules) if (e.device == device) return e.pace_of(per_cu);
+  return -1;
+}
+
+bool device_is_shared();  // cloudsc2_alloc.inc: do other ranks use this device at the same time?
+
+// workgroups per CU of every TL / AD variant that set_pace may be asked about (their occupancy, asked of the runtime), distinct
+std::vector<int> paced_kernel_occupancies() {
+  std::vector<int> out;
+  auto add = [&](const void* fn) {
+    int per_cu = 0;
+    if (!fn) return;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, 0) != hipSuccess || per_cu <= 0) { (void)hipGetLastError(); return; }
+    if (std::find(out.begin(), out.end(), per_cu) == out.end()) out.push_back(per_cu);
+  };
+  for (unsigned f = 0; f < 64; ++f) {
+    add((const void*)tl_variant(f));
+    add((const void*)ad_variant(f));
+    add((const void*)ad_reverse_variant(f));
+  }
+  return out;
+}
+
+// The synchronous moment.  Idempotent and cheap after the first call on a device (one mutex, one table lookup).
+int device_prepare() {
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+    (void)hipGetLastError();
+    return 0;  // (the callers' own HIP calls report what is wrong with the device)
+  }
+  {
+    std::lock_guard<std::mutex> lock(g_rule_mutex);
+    for (auto& e : g_rules)
+      if (e.device == dev && e.nl_rule >= 0) return 0;  // prepared (pace verdicts are taken in the same pass)
+  }
+  static const bool pace_off = getenv("CLOUDSC2_PACE") && atoi(getenv("CLOUDSC2_PACE")) == 0;
+  static const bool light_off = getenv("CLOUDSC2_NL_LIGHT") && atoi(getenv("CLOUDSC2_NL_LIGHT")) == 0;
+  DeviceRules r;
+  r.device = dev;
+  if (device_is_shared()) {  // the slots are not one launch's alone: both rules' premise is gone, nothing to probe
+    r.nl_rule = 0;
+  } else {
+    long long checked = 0, wrong = 0;
+    if (light_off) r.nl_rule = 0;
+    else if (probe_dispatch(cus, &checked, &wrong) == 0) {
+      r.nl_rule = wrong == 0 ? 1 : 0;
+      if (pace_verbose())
+        fprintf(stderr, "cloudsc2: dispatch probe on device %d: %lld of %lld waves sit on a SIMD with the predicted number of waves -> the lighter SIMDs' nap is %s\n",
+                dev, checked - wrong, checked, r.nl_rule ? "on" : "off");
+    } else if (pace_verbose()) fprintf(stderr, "cloudsc2: dispatch probe on device %d failed (%s): no verdict, no nap\n", dev, g_err.c_str());
+    if (!pace_off) {
+      for (int per_cu : paced_kernel_occupancies()) {
+        const int rc = probe_pace(cus, per_cu, &checked, &wrong);
+        if (rc == 0) r.pace.emplace_back(per_cu, wrong == 0 ? 1 : 0);
+        if (pace_verbose()) {
+          if (rc == 0)
+            fprintf(stderr, "cloudsc2: pace probe on device %d, %d workgroup(s) per CU: %lld of %lld workgroups ran where blockIdx mod slots says -> TL / AD pacing is %s\n",
+                    dev, per_cu, checked - wrong, checked, wrong == 0 ? "on" : "off");
+          else fprintf(stderr, "cloudsc2: pace probe on device %d, %d workgroup(s) per CU: no verdict (%s), no pacing\n", dev, per_cu, g_err.c_str());
+        }
+      }
+    }
+  }
+  if (r.nl_rule < 0) return 0;  // the probe itself failed: ask again at the next synchronous moment
   std::lock_guard<std::mutex> lock(g_rule_mutex);
   for (auto& e : g_rules)
-    if (e.device == device) return e.holds;
-  // the probe allocates, launches on the null stream and copies back: not inside a stream capture (this launch then goes without the
-  // nap, and the question stays open for the next one)
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(launch_stream, &cap) != hipSuccess) { (void)hipGetLastError(); return false; }
-  if (cap != hipStreamCaptureStatusNone) return false;
-  long long checked = 0, wrong = 0;
-  const bool ok = probe_dispatch(cus, &checked, &wrong) == 0 && wrong == 0;
-  if (getenv("CLOUDSC2_PACE_VERBOSE"))
-    fprintf(stderr, "cloudsc2: dispatch probe on device %d: %lld of %lld waves sit on a SIMD with the predicted number of waves -> the lighter SIMDs' nap is %s\n",
-            device, checked - wrong, checked, ok ? "on" : "off");
-  g_rules.push_back(DispatchRule{device, ok});
-  return ok;
+    if (e.device == dev) { e = r; return 0; }
+  g_rules.push_back(r);
+  return 0;
 }
 
 // Pacing of a TL / AD launch (cloudsc2_column.hpp: struct Pace): on when the launch is two to eight whole rounds of workgroups on the
 // slots the device has for THIS kernel (its occupancy, asked of the runtime once per kernel and device) plus a partial round that
-// fills at most half of them.
-// CLOUDSC2_PACE=0 switches it off (measurements).
-bool device_is_shared();  // cloudsc2_alloc.inc: do other ranks use this device at the same time?
+// fills at most half of them -- and the device's dispatcher was seen to behave as the rule needs (probe_pace above; read from the
+// cache here, never probed from a launch).  CLOUDSC2_PACE=0 switches it off (measurements).
 bool pace_plan(long long wgs, long long slots, int* first, int* recip_q16);
 template <class Args>
 void set_pace(Geom& g, KernelFn<Args> fn) {
@@ -580,31 +790,76 @@ void set_pace(Geom& g, KernelFn<Args> fn) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return; }
   static std::mutex mu;
-  static std::vector<std::tuple<const void*, int, long long>> cache;  // (kernel, device) -> workgroup slots
+  static std::vector<std::tuple<const void*, int, long long, int>> cache;  // (kernel, device) -> workgroup slots, workgroups per CU
   long long slots = 0;
+  int per_cu = 0;
   {
     std::lock_guard<std::mutex> lock(mu);
     for (auto& e : cache)
-      if (std::get<0>(e) == (const void*)fn && std::get<1>(e) == dev) slots = std::get<2>(e);
+      if (std::get<0>(e) == (const void*)fn && std::get<1>(e) == dev) { slots = std::get<2>(e); per_cu = std::get<3>(e); }
     if (!slots) {
-      int cus = 0, per_cu = 0;
+      int cus = 0;
       if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
           hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)fn, kBlock, 0) != hipSuccess || cus <= 0 || per_cu <= 0) {
         (void)hipGetLastError();
         return;
       }
       slots = (long long)cus * per_cu;
-      cache.emplace_back((const void*)fn, dev, slots);
+      cache.emplace_back((const void*)fn, dev, slots, per_cu);
     }
   }
   const long long wgs = (g.ncols_pad + kBlock - 1) / kBlock;
   int first = 0, recip = 0;
   if (!pace_plan(wgs, slots, &first, &recip)) return;
+  const int rule = cached_pace_rule(dev, per_cu);
+  if (rule != 1) {
+    static std::atomic<int> told{0};
+    if (pace_verbose() && told.fetch_add(1) < 4)
+      fprintf(stderr, "cloudsc2: launch of %lld workgroups on %lld slots NOT paced: %s\n", wgs, slots,
+              rule == 0 ? "the pace probe found this device's dispatcher off the rule" : "device not prepared (cloudsc2_device_prepare)");
+    return;
+  }
   g.pace_slots = (int)slots; g.pace_first = first; g.pace_recip_q16 = recip;
-  static const bool verbose = getenv("CLOUDSC2_PACE_VERBOSE") != nullptr;
-  if (verbose)
+  if (pace_verbose())
     fprintf(stderr, "cloudsc2: launch of %lld workgroups on %lld slots paced: %lld whole rounds + %d workgroups; the other %lld slots nap 1/%lld of every level\n",
             wgs, slots, wgs / slots, first, slots - first, wgs / slots);
+}
+
+// One-round NL launches: the lighter SIMDs of the fullest CUs yield (struct Pace: begin_light).  On only where every premise of
+// simd_population holds for THIS launch: the variant really runs three waves per SIMD (six workgroups per CU: its own occupancy,
+// asked of the runtime -- the evaporation variants run two and are left alone), all workgroups are resident at once, the fullest
+// CUs carry unequal numbers of waves on their SIMDs (2 x workgroups not a multiple of 4: otherwise nobody would nap and the launch
+// is the plain one), the device is this process's alone, its dispatcher was seen to follow the rule (cached verdict of
+// device_prepare; never probed here), and `fair` is the launcher's own decision, not the CLOUDSC2_FAIR override.
+// CLOUDSC2_NL_LIGHT = the nap in % of a level's measured time (0 = off; 10 / 15 / 20 measured: 15 best at 160 000 columns).
+void nl_light_nap(Geom& g, KernelFn<NlArgs> fn) {
+  static const int nl_light = getenv("CLOUDSC2_NL_LIGHT") ? atoi(getenv("CLOUDSC2_NL_LIGHT")) : 15;
+  static const bool fair_forced = getenv("CLOUDSC2_FAIR") && *getenv("CLOUDSC2_FAIR");
+  if (!g.fair || nl_light <= 0 || kBlock != 128 || fair_forced || !fn) return;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+    (void)hipGetLastError();
+    return;
+  }
+  static std::mutex mu;
+  static std::vector<std::tuple<const void*, int, int>> cache;  // (kernel, device) -> workgroups per CU
+  int per_cu = 0;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto& e : cache)
+      if (std::get<0>(e) == (const void*)fn && std::get<1>(e) == dev) per_cu = std::get<2>(e);
+    if (!per_cu) {
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)fn, kBlock, 0) != hipSuccess || per_cu <= 0) { (void)hipGetLastError(); return; }
+      cache.emplace_back((const void*)fn, dev, per_cu);
+    }
+  }
+  const long long wgs = (g.ncols_pad + kBlock - 1) / kBlock;
+  if (per_cu != 6 || wgs > (long long)cus * per_cu) return;
+  const long long q = wgs / cus, r = wgs % cus, fullest = q + (r ? 1 : 0);
+  if ((2 * fullest) % 4 == 0) return;  // equal SIMD loads in the CUs the launch ends with
+  if (cached_nl_rule(dev) != 1) return;  // (a shared device is recorded as "rule off" by device_prepare)
+  g.pace_slots = cus; g.pace_first = (int)q; g.pace_recip_q16 = (int)(65536.0 * nl_light / 100.0);
+  g.fair |= 4 | ((int)r << 8);
 }
 
 // The rule itself (pure arithmetic; cloudsc2_pace_plan exposes it to the tests): `wgs` workgroups on `slots` slots.
@@ -682,6 +937,44 @@ int cloudsc2_dispatch_probe(long long* waves_checked, long long* waves_wrong) {
   HIP_TRY(hipGetDevice(&dev));
   HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   return probe_dispatch(cus, waves_checked, waves_wrong);
+}
+
+int cloudsc2_pace_probe(int workgroups_per_cu, long long* workgroups_checked, long long* workgroups_wrong) {
+  if (!workgroups_checked || !workgroups_wrong) return fail(CLOUDSC2_EINVAL, "cloudsc2_pace_probe: NULL argument");
+  if (!device_ok()) return fail(CLOUDSC2_ENODEVICE, "no HIP device available (this library has no CPU path)");
+  int dev = 0, cus = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  return probe_pace(cus, workgroups_per_cu, workgroups_checked, workgroups_wrong);
+}
+
+int cloudsc2_device_prepare(void) {
+  if (!device_ok()) return fail(CLOUDSC2_ENODEVICE, "no HIP device available (this library has no CPU path)");
+  return device_prepare();
+}
+
+int cloudsc2_device_rules(int workgroups_per_cu, int* nl_nap, int* pacing) {
+  int dev = 0;
+  if (!device_ok() || hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return fail(CLOUDSC2_ENODEVICE, "no HIP device available (this library has no CPU path)"); }
+  if (nl_nap) *nl_nap = cached_nl_rule(dev);
+  if (pacing) *pacing = cached_pace_rule(dev, workgroups_per_cu);
+  return 0;
+}
+
+int cloudsc2_kernel_occupancy(int kernel, int flags, int* workgroups_per_cu) {
+  if (!workgroups_per_cu) return fail(CLOUDSC2_EINVAL, "cloudsc2_kernel_occupancy: NULL argument");
+  if (!device_ok()) return fail(CLOUDSC2_ENODEVICE, "no HIP device available (this library has no CPU path)");
+  const void* fn = nullptr;
+  switch (kernel) {
+    case 0: fn = (const void*)nl_variant((unsigned)flags); break;
+    case 1: fn = (const void*)tl_variant((unsigned)flags); break;
+    case 2: fn = (const void*)ad_variant((unsigned)flags); break;
+    case 3: fn = (const void*)ad_reverse_variant((unsigned)flags); break;
+    default: break;
+  }
+  if (!fn) return fail(CLOUDSC2_EINVAL, "cloudsc2_kernel_occupancy: no such kernel variant in this build");
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(workgroups_per_cu, fn, kBlock, 0));
+  return 0;
 }
 
 int cloudsc2_pace_plan(long long workgroups, long long slots, int* whole_rounds, int* fast_first, int* nap_recip_q16) {
@@ -803,22 +1096,9 @@ int cloudsc2_nl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
   if (!prm->lphylin && !prm->ldrain1d) f |= C2F_NOLIN;  // cloudsc2.F90:349 (CLOUDSC2TL / CLOUDSC2AD have the LPHYLIN form only)
   if ((f & C2F_NOLIN) && (f & C2F_PERT))
     return fail(CLOUDSC2_EINVAL, "pert_lambda != 0 with LPHYLIN = 0: the perturbed runs of the Taylor test exist in the LPHYLIN form only");
-  args.g.fair = nl_fair(g.ncols_pad, args.c.evap != 0);
-  // one-round launches: the lighter SIMDs of the fullest CUs yield (struct Pace: begin_light); CLOUDSC2_NL_LIGHT = the nap in % of a
-  // level's measured time (0 = off; 10 / 15 / 20 measured: 15 best at 160 000 columns, neutral where no CU has unequal SIMDs)
-  static const int nl_light = getenv("CLOUDSC2_NL_LIGHT") ? atoi(getenv("CLOUDSC2_NL_LIGHT")) : 15;
-  if (args.g.fair && nl_light > 0 && kBlock == 128) {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0 &&
-        !device_is_shared() && dispatch_rule_holds(dev, cus, (hipStream_t)stream)) {
-      const long long wgs = (g.ncols_pad + kBlock - 1) / kBlock;
-      args.g.pace_slots = cus; args.g.pace_first = (int)(wgs / cus); args.g.pace_recip_q16 = (int)(65536.0 * nl_light / 100.0);
-      args.g.fair |= 4 | ((int)(wgs % cus) << 8);
-    } else {
-      (void)hipGetLastError();
-    }
-  }
   if (fits_off32(g, nproma, nlev, {s.full, s.half, s.cml, s.clv, s.loc, (long long)zero_plane.block_stride})) f |= C2F_OFF32;
+  args.g.fair = nl_fair(g.ncols_pad, args.c.evap != 0);
+  nl_light_nap(args.g, nl_variant(f));
   return launch_variant(nl_variant(f), args, g.ncols_pad, (hipStream_t)stream);
 }
 

@@ -160,10 +160,11 @@ typedef struct cloudsc2_outputs {
  * pert_lambda != 0: every input x is replaced on load by x + pert_lambda*(0.01*x), the perturbed state
  * of the Taylor test (cloudsc_driver_tl_mod.F90:156-171,200-215); with fused SATUR, PQS is perturbed the
  * same way after SATUR on the unperturbed PAP,PT (:159,:203).
- * Asynchronous on `stream` -- with one exception per process and device: the first launch that is ONE round of waves (<= 196 608
- * columns on MI355X) first runs the 40 us dispatch probe described at cloudsc2_dispatch_probe below (a small allocation, a launch on
- * the NULL stream and a copy back: it synchronises with the null stream once); not while `stream` is capturing, and not with
- * CLOUDSC2_NL_LIGHT=0. */
+ * Asynchronous on `stream`, always: no launcher of this library allocates, copies or synchronises on behalf of the launch
+ * heuristics below -- they only read what cloudsc2_device_prepare cached.  (The one thing a launcher may create is the device copy
+ * of the per-level table of a CETA it sees for the first time: a 3 KB allocation and a copy through a private non-blocking stream,
+ * with the thread's capture mode relaxed; a launch on a stream that is ITSELF being captured needs that table to exist already --
+ * any earlier launch or driver call with the same CETA made it.) */
 int cloudsc2_nl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
                        const cloudsc2_inputs* in, const cloudsc2_outputs* out, cloudsc2_field zero_plane,
                        double pert_lambda, void* stream);
@@ -179,7 +180,8 @@ int cloudsc2_satur_launch(const cloudsc2_params* prm, int nproma, int nlev, int 
  * workgroups on the device's slots; when it is two to eight whole rounds plus a partial one that fills at most half of the slots
  * (160 000 columns on MI355X: 1250 workgroups on 512 slots), the workgroups whose slot has one workgroup less to run nap at every
  * level for 1/k of the level's measured time, leaving their share of the bandwidth to the slots on the critical path: TL -5 %, AD
- * -7 % at 160 000 columns (profiles/r04_pacing_ab.txt).  CLOUDSC2_PACE=0 in the environment switches it off,
+ * -7 % at 160 000 columns (profiles/r04_pacing_ab.txt) -- on a device whose dispatcher cloudsc2_device_prepare
+ * (below) has seen to be in-order and slot-stable, which is what the rule rests on.  CLOUDSC2_PACE=0 in the environment switches it off,
  * CLOUDSC2_PACE_VERBOSE=1 reports paced launches on stderr.  cloudsc2_pace_plan is the rule itself (pure arithmetic, no device):
  * for `workgroups` (of 128 threads) on `slots` workgroup slots it returns 1 when the launch would be paced, with the number of whole
  * rounds, the number of leading positions of every round that form the fast class, and 65536 / k (the nap as a share of a level). */
@@ -191,11 +193,38 @@ int cloudsc2_pace_plan(long long workgroups, long long slots, int* whole_rounds,
  * `block` of a launch of `workgroups` 128-thread blocks on `cus` CUs, *mine = waves of the launch on its SIMD, *most = on the fullest
  * SIMD of its CU.  tools/wave_times.py checks it against the hardware's own record (HW_ID) wave by wave. */
 int cloudsc2_simd_population(long long workgroups, int cus, long long block, int wave_in_block, int* mine, int* most);
-/* The library does not take that rule on trust: before it is used for the first time on a device (once per process) a 40 us probe
- * launch of the NL kernel's shape records where its waves run (HW_ID) and the rule is checked wave by wave; one miss -- another
- * dispatcher, other work on the device at that moment -- and the nap stays off for the device.  cloudsc2_dispatch_probe runs the
- * same probe on the current device and returns the counts (GPU tests; CLOUDSC2_PACE_VERBOSE=1 prints the library's own verdict). */
+/* The library takes neither rule on trust, and checks neither from a launch.  cloudsc2_device_prepare is the one SYNCHRONOUS moment:
+ * on the calling thread's current device, once per device and process (later calls return at once), it runs
+ *   - the dispatch probe of the NL rule: a 40 us launch of the NL kernel's shape whose waves record where they run (HW_ID); the
+ *     rule is checked wave by wave, one miss -- another dispatcher, other work on the device at that moment -- and the lighter
+ *     SIMDs' nap stays off for the device;
+ *   - the pace probe of the TL / AD rule, for every occupancy (workgroups per CU) a TL / AD kernel of this build has: a 130 us launch
+ *     of 2.44 rounds of workgroups that do nothing but stay as long as their class would (fast 40 us; napping 60 us) and record
+ *     where and when they ran; per CU the workgroups it ran must be (k+1) of the fast class per fast workgroup of its first round
+ *     and k of the slow class per slow one, and the whole first round must have been resident at once.  One miss -- a dispatcher
+ *     that is not in-order and slot-stable, CU masking, another partition mode's queueing -- and TL / AD launches are not paced.
+ * Each probe: one small allocation, two launches on a private non-blocking stream, one copy back, with the thread's stream-capture
+ * mode relaxed meanwhile (a graph capture going on elsewhere in the process is not disturbed); a probe that ends in a HIP error
+ * leaves no verdict and is repeated by the next call.  The library calls it from every entry point that allocates device memory
+ * (cloudsc2_device_malloc*, cloudsc2_state_create, the host-array drivers' workspace), so callers of those never need to.  A caller
+ * that brings its OWN device memory to the kernel-level entry points and wants the naps calls cloudsc2_device_prepare once at
+ * start-up; without it every launch simply runs unpaced (results are the same bits either way).  CLOUDSC2_PACE_VERBOSE=1 prints
+ * the verdicts.  cloudsc2_dispatch_probe / cloudsc2_pace_probe run one probe and return its counts without caching anything (GPU
+ * tests); cloudsc2_device_rules returns the cached verdicts of the current device (1 on, 0 off, -1 never probed);
+ * cloudsc2_kernel_occupancy the workgroups per CU of one kernel variant (kernel 0 NL, 1 TL, 2 AD both sweeps, 3 AD reverse sweep;
+ * flags = its C2F_* variant bits, cloudsc2_column.hpp) as the runtime reports them.
+ *
+ * What a caller with its own hipMalloc should expect.  The same kernel on the same data runs 0.78 or 0.92 ms (NL, 160 000 columns:
+ * 0.73 vs 0.63 of the HBM peak) depending on WHERE in the HBM the state lies (profiles/r02_hbm_placement.md); cloudsc2_device_malloc*
+ * search for a good place, a plain first hipMalloc of a process typically lands on a slow one (bench line:
+ * roofline.unplaced_first_allocation).  A host model that allocates its own state gets the kernels' full rate by taking that one
+ * allocation from cloudsc2_device_malloc_state (ordinary hipMalloc memory, freed with cloudsc2_device_free), or by allocating
+ * candidates itself and keeping the one cloudsc2_device_probe times fastest. */
+int cloudsc2_device_prepare(void);
 int cloudsc2_dispatch_probe(long long* waves_checked, long long* waves_wrong);
+int cloudsc2_pace_probe(int workgroups_per_cu, long long* workgroups_checked, long long* workgroups_wrong);
+int cloudsc2_device_rules(int workgroups_per_cu, int* nl_nap, int* pacing);
+int cloudsc2_kernel_occupancy(int kernel, int flags, int* workgroups_per_cu);
 int cloudsc2_tl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, int nlev, int ngptot,
                        const cloudsc2_inputs* traj_in, const cloudsc2_outputs* traj_out,
                        const cloudsc2_inputs* pert_in, const cloudsc2_outputs* pert_out, void* stream);

@@ -956,3 +956,65 @@ def test_the_dispatch_rule_holds_on_this_device():
     # measured 0 / 0 / 0 on every box; one disturbed probe (another process touching the GPU) is tolerated here -- the library itself
     # then simply leaves the nap off -- a rule that is wrong shows in all three
     assert min(wrongs) == 0 and sorted(wrongs)[1] == 0, wrongs
+
+
+def test_the_pace_rule_holds_on_this_device():
+    """TL / AD pacing rests on a rule about the ORDER in which the dispatcher hands workgroups to freed slots (Pace::begin decides
+    from blockIdx mod slots alone which workgroups sit on the launch's critical path).  The library checks it on the device at a
+    synchronous moment before it ever paces a launch (cloudsc2_device_prepare: a 130 us probe of 2.44 rounds of workgroups that only
+    stay as long as their class would, and record where and when they ran; one miss and pacing stays off); here the same probe
+    through the ABI, for the occupancy the fp64 TL / AD kernels really have, and the cached verdicts the launchers read."""
+    import ctypes as C
+
+    import torch
+
+    torch.cuda.synchronize()
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    per_cu = C.c_int()
+    occ = {}
+    for kernel, flags, name in ((1, 1 | 8 | 32, "tl"), (2, 1 | 32, "ad"), (3, 1 | 32, "ad_reverse")):  # C2F_QSAT [| C2F_TRAJ] | C2F_OFF32
+        B.check(B.lib.cloudsc2_kernel_occupancy(kernel, flags, C.byref(per_cu)))
+        occ[name] = per_cu.value
+    print("workgroups per CU:", occ)
+    if not B.SINGLE:
+        assert set(occ.values()) == {2}, occ  # one wave per SIMD: 311 / 308 registers
+    for pc in sorted(set(occ.values())):
+        wrongs = []
+        for _ in range(3):
+            checked, wrong = C.c_longlong(), C.c_longlong()
+            B.check(B.lib.cloudsc2_pace_probe(pc, C.byref(checked), C.byref(wrong)))
+            slots = cus * pc
+            assert checked.value == 2 * slots + slots * 113 // 256
+            wrongs.append(wrong.value)
+        print(f"pace probe, {pc} workgroup(s) per CU: workgroups off the rule in three probes:", wrongs)
+        assert min(wrongs) == 0 and sorted(wrongs)[1] == 0, wrongs  # (one disturbed probe tolerated, as for the dispatch rule)
+    # the synchronous moment itself, and what the launchers will read afterwards
+    B.check(B.lib.cloudsc2_device_prepare())
+    nap, pace = C.c_int(-2), C.c_int(-2)
+    B.check(B.lib.cloudsc2_device_rules(occ["tl"], C.byref(nap), C.byref(pace)))
+    print("cached verdicts: NL nap", nap.value, "TL/AD pacing", pace.value)
+    assert nap.value in (0, 1) and pace.value in (0, 1)  # probed (an undisturbed box gives 1 / 1)
+    B.check(B.lib.cloudsc2_device_rules(7, C.byref(nap), C.byref(pace)))
+    assert pace.value == -1  # no kernel of the build has that occupancy: never probed, never paced
+    assert B.lib.cloudsc2_kernel_occupancy(9, 0, C.byref(per_cu)) != 0
+
+
+def test_launches_under_stream_capture_are_plain_kernel_nodes():
+    """No launcher allocates, copies or synchronises on behalf of the launch heuristics (round 4's NL launcher ran its dispatch probe
+    from the first one-round launch): an NL and a TL launch recorded into a graph while the stream is capturing -- the first launches
+    of a FRESH process whose device was prepared by the state's allocation -- replay to the bits of the eager launches
+    (tools/capture_probe.py), and the captured TL launch was paced from the cached verdict."""
+    import subprocess
+    import sys
+
+    from tests.util import ROOT
+
+    e = {k: v for k, v in os.environ.items() if not k.startswith(("CLOUDSC2_PACE", "CLOUDSC2_NL_LIGHT"))}
+    for mode in ("cold", "warm"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "capture_probe.py"), mode], capture_output=True, text=True, timeout=600,
+                           env={**e, "CLOUDSC2_PACE_VERBOSE": "1"})
+        assert r.returncode == 0 and f"CAPTURE OK {mode}" in r.stdout, (mode, r.stdout[-500:], r.stderr[-3000:])
+        # the device was prepared by the allocation (both probes ran there, before any launch)
+        assert "dispatch probe on device" in r.stderr and "pace probe on device" in r.stderr, r.stderr[-3000:]
+        if "TL / AD pacing is on" in r.stderr:
+            assert r.stderr.index("pace probe on device") < r.stderr.index("launch of 1094 workgroups on 512 slots paced"), r.stderr[-3000:]
