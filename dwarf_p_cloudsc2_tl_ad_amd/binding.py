@@ -182,6 +182,8 @@ def _load() -> C.CDLL:
     lib.cloudsc2_dispatch_probe.restype = C.c_int
     lib.cloudsc2_pace_probe.argtypes = [C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     lib.cloudsc2_pace_probe.restype = C.c_int
+    lib.cloudsc2_synthetic_table.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double] + [C.POINTER(C.c_double)] * 12
+    lib.cloudsc2_synthetic_table.restype = C.c_int
     lib.cloudsc2_device_prepare.argtypes = []
     lib.cloudsc2_device_prepare.restype = C.c_int
     lib.cloudsc2_device_rules.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -228,7 +230,7 @@ EXPORTED = ("cloudsc2_params_default", "cloudsc2_last_error", "cloudsc2_device_a
             "cloudsc2_device_malloc", "cloudsc2_device_free", "cloudsc2_device_malloc_info", "cloudsc2_device_malloc_counts", "cloudsc2_pace_plan", "cloudsc2_simd_population", "cloudsc2_dispatch_probe", "cloudsc2_pace_probe", "cloudsc2_device_prepare", "cloudsc2_device_rules", "cloudsc2_kernel_occupancy", "cloudsc2_device_probe", "cloudsc2_device_malloc_state",
             "cloudsc2_state_create", "cloudsc2_state_destroy", "cloudsc2_state_field", "cloudsc2_state_blocking", "cloudsc2_state_expand",
             "cloudsc2_state_upload", "cloudsc2_state_download", "cloudsc2_state_nl", "cloudsc2_state_tl_taylor",
-            "cloudsc2_state_ad_symmetry", "cloudsc2_state_validate")
+            "cloudsc2_state_ad_symmetry", "cloudsc2_state_validate", "cloudsc2_synthetic_table")
 
 # field ids of the resident-state API (enum in include/cloudsc2_hip.h)
 F_FULL = {"PT": 0, "PQ": 1, "PAP": 2, "PAPH": 3, "PLU": 4, "PLUDE": 5, "PMFU": 6, "PMFD": 7, "PA": 8, "PSUPSAT": 9, "PCOVPTOT": 10,

@@ -1492,6 +1492,46 @@ int cloudsc2_validate_header(char* buf, int buflen) {
   return 0;
 }
 
+// The synthetic KLON-column atmosphere that stands in for config-files/input.h5 (not distributed: .MISSING_LARGE_BLOBS) -- ONE
+// implementation for every front end (the Fortran mains, the Python harness), so that they all run the same bits:
+// the Taylor test's verdict is decided by round-off, and tables that differ in the last place of an exp() or a power (numpy's, flang's
+// and glibc's differ: up to 9e-15 relative in PQ) give different verdicts for the same library and size (profiles/EXPERIMENTS.md section 8).
+// Recipe of SURVEY.md 8d: every column carries cloud and precipitates (the reference's Taylor test STOPs on a block without active
+// statistics), none is near-trivial (the adjoint test is relative per column).  Arrays are (nlev[+1], klon) row-major = Fortran
+// (KLON, KLEV[+1]), always double.
+#pragma clang fp contract(off)
+int cloudsc2_synthetic_table(int klon, int nlev, double rd, double rv, double rtt, double* pt, double* pq, double* pap, double* paph,
+                             double* plu, double* plude, double* pmfu, double* pmfd, double* pql, double* pqi, double* tend_t,
+                             double* tend_q) {
+  if (klon < 1 || nlev < 1) return fail(CLOUDSC2_EINVAL, "cloudsc2_synthetic_table: bad dimensions");
+  if (!pt || !pq || !pap || !paph || !plu || !plude || !pmfu || !pmfd || !pql || !pqi || !tend_t || !tend_q)
+    return fail(CLOUDSC2_EINVAL, "cloudsc2_synthetic_table: NULL array");
+  const double r2es = 611.21 * rd / rv, r3les = 17.502, r4les = 32.19, ps = 101325.0;
+  std::vector<double> ph((size_t)nlev + 1);
+  for (int k = 0; k <= nlev; ++k) ph[k] = 1.0 + (ps - 1.0) * pow((double)k / (double)nlev, 2.2);
+  for (int ig = 0; ig < klon; ++ig) {
+    const double h1 = (double)((37LL * ig) % 100) / 100.0, h2 = (double)((61LL * ig + 13) % 100) / 100.0,
+                 h3 = (double)((89LL * ig + 7) % 100) / 100.0;
+    for (int k = 0; k <= nlev; ++k) paph[(size_t)k * klon + ig] = ph[k];
+    for (int k = 0; k < nlev; ++k) {
+      const size_t i = (size_t)k * klon + ig;
+      const double p = 0.5 * (ph[k] + ph[k + 1]), eta = p / ps;
+      const double t = fmax(205.0 + 10.0 * h2, (255.0 + 45.0 * h1) * pow(eta, 0.19));
+      const double u = (eta - 0.3 - 0.5 * h2) / 0.18;
+      const double rh = 0.35 + (0.72 + 0.1 * h3) * exp(-(u * u));
+      const double e_liq = r2es * exp(r3les * (t - rtt) / (t - r4les));
+      const bool moist = rh > 0.8, conv = h3 > 0.6 && eta > 0.35 && eta < 0.9;
+      pap[i] = p; pt[i] = t; pq[i] = rh * fmin(0.5, e_liq / p);
+      pql[i] = 1e-7 * eta + (moist ? 2e-5 * h1 * eta : 0.0);
+      pqi[i] = 1e-7 * (1.0 - eta) + (moist ? 1e-5 * (1.0 - h1) : 0.0);
+      plu[i] = conv ? 3e-4 * h3 : 0.0; pmfu[i] = conv ? 0.05 * h3 : 0.0; pmfd[i] = conv ? -0.01 * h3 : 0.0;
+      plude[i] = (conv && eta < 0.5) ? 1e-6 * h3 : 0.0;
+      tend_t[i] = 1e-5 * (h1 - 0.5); tend_q[i] = 1e-9 * (h2 - 0.5);
+    }
+  }
+  return 0;
+}
+
 int cloudsc2_taylor_verdict(const double znormg_in[10], int* itest_out) {
   // cloudsc_driver_tl_mod.F90:272-311
   double z[10];

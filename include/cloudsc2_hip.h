@@ -411,6 +411,17 @@ int cloudsc2_state_ad_symmetry(cloudsc2_state* state, const cloudsc2_params* prm
 int cloudsc2_state_validate(cloudsc2_state* state, int field, int ndim, const cloudsc2_real* ref_table, int klon, int period,
                             long long start, double stats[5]);
 
+/* The synthetic KLON-column atmosphere every front end of this repository loads when config-files/input.h5 is absent (it is not
+ * distributed with the reference: .MISSING_LARGE_BLOBS) -- what CLOUDSC2_ARRAY_STATE_LOAD (cloudsc2_array_state_mod.F90:153-204) would
+ * read from the file: PT PQ PAP PAPH(nlev+1) PLU PLUDE PMFU PMFD PCLV(QL) PCLV(QI) TENDENCY_CML%T TENDENCY_CML%Q, each (nlev[+1], klon)
+ * row-major = Fortran (KLON, KLEV[+1]), always double; everything else of the state is zero.  Pure host code, one implementation for
+ * the Fortran mains and the Python harness: the Taylor test's verdict is decided by round-off, so tables that differ
+ * in the last place (numpy's, flang's and glibc's exp / pow do) give different verdicts for the same library and size.  rd, rv, rtt:
+ * YOMCST's RD, RV, RTT (287.0597, 461.5250, 273.16). */
+int cloudsc2_synthetic_table(int klon, int nlev, double rd, double rv, double rtt, double* pt, double* pq, double* pap, double* paph,
+                             double* plu, double* plude, double* pmfu, double* pmfd, double* pql, double* pqi, double* tend_t,
+                             double* tend_q);
+
 /* Verdict logic of the two self-tests, pure host code (no device needed).
  * cloudsc2_taylor_verdict: cloudsc_driver_tl_mod.F90:272-311; znormg = raw ratios; returns 1 = PASSED;
  *   *itest = penalty / error code (13 when no lambda <= 1e-4 reaches |1-ratio| < 0.5).

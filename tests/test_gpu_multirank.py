@@ -38,8 +38,8 @@ def _summary(out: str) -> dict:
 
 def test_two_ranks_split_the_columns_and_reduce_the_statistics(tmp_path):
     exe = os.path.join(BLD, "dwarf-cloudsc2-nl")
-    one, err1 = _run([exe, 1, 3000, 64], cwd=tmp_path)
-    two, err2 = _run([LAUNCH, 2, exe, 1, 3000, 64], env={"CLOUDSC2_COMM": "shm"}, cwd=tmp_path)
+    one, err1 = _run([exe, 1, 3000, 64], env={"CLOUDSC2_RESIDENT": "0"}, cwd=tmp_path)  # (the reference flow alone: one header, one table)
+    two, err2 = _run([LAUNCH, 2, exe, 1, 3000, 64], env={"CLOUDSC2_COMM": "shm", "CLOUDSC2_RESIDENT": "0"}, cwd=tmp_path)
     assert "NUMPROC=1," in err1 and "NUMPROC=2," in err2
     assert "NGPBLKS=24" in err2                      # 1500 columns per rank (dwarf_cloudsc.F90:64-69) in blocks of 64
     assert err2.count("NUMPROC=2,") == 1             # rank 0 alone prints the header, and one table row per rank
@@ -80,7 +80,7 @@ def test_rccl_transport_with_a_one_rank_communicator(tmp_path):
 
 def test_resident_mode_of_the_mains(tmp_path):
     exe = os.path.join(BLD, "dwarf-cloudsc2-nl")
-    host, _ = _run([exe, 4, 16000, 32], cwd=tmp_path)
+    host, _ = _run([exe, 4, 16000, 32], env={"CLOUDSC2_RESIDENT": "0"}, cwd=tmp_path)
     res, err = _run([exe, 4, 16000, 32], env={"CLOUDSC2_RESIDENT": "1"}, cwd=tmp_path)
     assert "state resident on the GPU" in err
     a, b = _summary(host), _summary(res)
