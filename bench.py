@@ -17,11 +17,14 @@ The state is the first and only allocation of the process and comes from the lib
 not search.  `roofline.unplaced_first_allocation`
 is the same measurement in a fresh process with the placement switched off.
 
-The line also carries `cpu_baseline` (the reference on the host cores, rank 0 at N=1) and, at N=1, from child processes run
-after the measurement: `companion_kernels` (the same bench for TL and AD -- BASELINE.json's metric names all three),
-`target_config` (NL at 1 048 576 columns, north_star's target), `host_array_driver` (the PCIe-inclusive rate of the reference-signature
-path, never `value`) and `self_tests` (the Taylor test and the adjoint test on a resident state of the same size: verdicts and kernel
-time); none of them is inside the timed region.
+The line also carries `cpu_baseline` (the reference on rank 0's host cores) and, at N=1, from child processes run
+after the measurement: `companion_kernels` (the same bench for TL and AD -- BASELINE.json's metric names all three; AD with its
+design floor, ad_design_floor), `nproma_sweep` (NL at NPROMA 32 / 64 / 128 / 256, BASELINE configs[1]), `target_config` (NL at
+1 048 576 columns, north_star's target), `host_array_driver` (the PCIe-inclusive rate of the reference-signature path, never `value`)
+and `self_tests` (the Taylor test and the adjoint test on a resident state of the same size: verdicts and kernel time).  At N > 1
+(BASELINE configs[4]: NL + TL + AD on the node) `companion_kernels` comes from every rank timing TL and AD IN-PROCESS on its own
+columns after the timing line is out -- same protocol, value = all ranks' columns over the MAX-over-ranks time, per-rank kernel times
+-- and `cpu_baseline` from rank 0 after the last collective, while --budget-s has room.  None of this is inside the timed region.
 """
 from __future__ import annotations
 
@@ -294,6 +297,91 @@ def spawn_ranks(ngpus: int, argv, rehearsal: bool = False, budget_s: float = 420
     return 0
 
 
+def build_step(c2, args, tab, prm, kernel, dev, stream, col0):
+    """One kernel of the path on this rank's columns, ready to be timed: (state, step(), algorithmic bytes per column, what must stay
+    alive, the kernel's name, the allocator's placement record).
+
+    The state: tiled on the device from the 100-column table (cloudsc2_expand_launch: no host copy exists) into ONE arena
+    from the library's allocator, which places it (cloudsc2_device_malloc_state: candidate allocations spanning 96 GiB, judged by
+    the NL sweep itself for a state alone, by two generic streams when perturbation sets follow; profiles/r02_hbm_placement.md).
+    What any caller of the C ABI gets, no search here.
+    TL / AD: the perturbation set (increments + outputs) and the adjoint's carry plane live in the SAME allocation as the state,
+    as in the library's own test drivers (measured: TL 1.65 vs 1.66-1.72 ms, AD 3.04 vs 3.18-3.22 ms for a separate allocation)."""
+    nbk = (args.ngptot + args.nproma - 1) // args.nproma
+    nlev_t = tab["PT"].shape[0]
+    reserve = 0
+    if kernel != "nl":
+        reserve = c2.FlatFields.pair_bytes(nbk, nlev_t, args.nproma) + (nbk * nlev_t * args.nproma * c2.binding.REAL_BYTES + 4096 if (kernel == "ad" and args.levapls2) else 0)
+    ds = c2.DeviceState.from_table(tab, args.nproma, args.ngptot, dev, start=col0, reserve=reserve)
+    placement = dict(getattr(ds.arena, "info", {}))
+    nlev = ds.nlev
+    if kernel == "nl":
+        step, bpc, keep = (lambda: ds.nl(prm, stream)), c2.bytes_per_column(nlev, "nl_driver"), ds
+        kname = "nl_kernel<F> (SATUR + CLOUDSC2 fused; fast math, no evaporation branch, 32-bit offsets when buffers < 4 GiB)"
+    else:
+        ds.satur(prm, stream)
+        inc, dout = c2.FlatFields.pair(ds.nb, ds.nlev, ds.nproma, dev, arena=ds.arena)  # increments + TL outputs
+        ds.increments(zero_supsat=(kernel == "ad"), into=inc)
+        if kernel == "tl":
+            step, bpc, keep = (lambda: ds.tl(prm, inc, dout, stream)), c2.bytes_per_column(nlev, "tl"), (ds, inc, dout)
+            kname = ("tl_kernel<C2F_QSAT|C2F_TRAJ> (CLOUDSC2TL: trajectory evaluated in the sweep, its ten outputs and the ten TL outputs stored; "
+                     "launches of a few partial rounds of workgroups are paced, CLOUDSC2_PACE=0 switches that off)")
+        else:
+            ds.tl(prm, inc, dout, stream)  # leaves the trajectory outputs (PFPLSL5 / PFPLSN5) in the state
+            # the cover-checkpoint plane exists only with the evaporation branch (its one reader)
+            scratch = ds.arena.take((ds.nb, ds.nlev, ds.nproma)) if args.levapls2 else None
+            step = lambda: ds.ad(prm, inc, dout, scratch, stream, assign=args.ad_assign, sweep=args.ad_sweep)  # noqa: E731
+            bpc = c2.bytes_per_column(nlev, "ad" if args.ad_sweep == "both" else "ad_reverse")
+            if args.levapls2:  # + the checkpoint plane: written by the forward sweep, read by the reverse sweep
+                bpc += c2.bytes_per_column(nlev, "ad_ckpt") // (1 if args.ad_sweep == "both" else 2)
+            kname = ("ad_kernel<C2F_QSAT> (CLOUDSC2AD: trajectory pass + reverse pass; partial rounds paced)" if args.ad_sweep == "both" else
+                     "ad_reverse_kernel<C2F_QSAT> (reverse sweep of CLOUDSC2AD alone; carries from the state's PFPLSL5 / PFPLSN5; partial rounds paced)")
+            if args.ad_assign:  # the 16 old input adjoints (15 full-level planes + PAPH's nlev+1) are not read
+                bpc -= c2.bytes_per_column(nlev, "ad_old_adjoints")
+                kname = kname.replace("<C2F_QSAT>", "<C2F_QSAT|C2F_ASSIGN>") + " [x = A^T y: old input adjoints not read]"
+            keep = (ds, inc, dout, scratch)
+    return ds, step, bpc, keep, kname, placement
+
+
+def ad_design_floor(c2, nlev, kernel_ms, ngptot, peak_gbs=HBM_PEAK_GBS):
+    """CLOUDSC2AD, both sweeps, accumulate form: SURVEY 8d's 85 608 B per column assume the trajectory survives on chip between the
+    forward pass (cloudsc2ad.F90:366-866) and the reverse pass (:877-1740).  A 137-level column's trajectory inputs are 17 544 B; a
+    CU's 256 resident columns would need 4.5 MB of the 160 KiB LDS.  What a two-pass adjoint must move is therefore 85 608 + the
+    second read of the 2 193 trajectory-input doubles = 103 152 B per column (the PMC counters see 1.198 x 85 608 = 102.6 KB), and
+    the fraction of the peak against THAT figure is what the kernel can be held to.  Pure arithmetic (tests/test_bench_launch.py)."""
+    floor = c2.bytes_per_column(nlev, "ad_design_floor")
+    return {"bytes_per_column_design_floor": int(floor),
+            "frac_design_floor": floor * ngptot / (kernel_ms * 1e-3) / 1e9 / peak_gbs,
+            "design_floor": "85 608 B (SURVEY 8d) + the reverse pass's second read of the 2 193 trajectory-input doubles: a 137-level "
+                            "trajectory does not survive on chip between the two passes (cloudsc2ad.F90:366-866, :877-1740)"}
+
+
+def timed_steps(torch, dev, stream, step, steps, warmup, barrier=None):
+    """W warm-up + SETTLE_LAUNCHES untimed launches, then exactly `steps` launches between a barrier + synchronize on both sides.
+    Returns (wall seconds of the K steps on this rank, per-launch device times from HIP events on the launch stream)."""
+    for _ in range(max(warmup, 0)):
+        step()
+    for _ in range(SETTLE_LAUNCHES):  # after an idle second the GPU needs ~15 launches (12 ms) to reach its steady time again, whatever the memory
+        # (tools/settle_series.py: 0.93 0.84 0.86 0.89 0.87 ... 0.82 ms; the same after a 2 s pause); reported as `settle_launches`,
+        # next to the W warm-up steps the caller asked for (`warmup_total` = both)
+        step()
+    torch.cuda.synchronize(dev)
+    if barrier:
+        barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record(stream)
+        step()
+        b.record(stream)
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0  # this rank's K steps, device work included; the closing barrier follows, then the MAX over ranks
+    if barrier:
+        barrier()
+    return elapsed, np.array([a.elapsed_time(b) for a, b in ev])  # per-launch device time on the launch stream
+
+
 def child_bench(extra_args, env=None, timeout=900):
     """Run this script as a fresh child process (own device memory, own placement) and return its JSON line."""
     import subprocess
@@ -439,45 +527,8 @@ def main():
     col0 = rank * args.ngptot  # weak scaling: rank r owns global columns [r*NGPTOT, (r+1)*NGPTOT)
     stream = torch.cuda.current_stream(dev)
 
-    # The state: tiled on the device from the 100-column table (cloudsc2_expand_launch: no host copy exists) into ONE arena
-    # from the library's allocator, which places it (cloudsc2_device_malloc_state: candidate allocations spanning 96 GiB, judged by
-    # the NL sweep itself for a state alone, by two generic streams when perturbation sets follow; profiles/r02_hbm_placement.md).
-    # This is the first and only state of the process: what any caller of the C ABI gets, no search here.
-    # TL / AD: the perturbation set (increments + outputs) and the adjoint's carry plane live in the SAME allocation as the state,
-    # as in the library's own test drivers (measured: TL 1.65 vs 1.66-1.72 ms, AD 3.04 vs 3.18-3.22 ms for a separate allocation)
-    nbk = (args.ngptot + args.nproma - 1) // args.nproma
-    nlev_t = tab["PT"].shape[0]
-    reserve = 0
-    if args.kernel != "nl":
-        reserve = c2.FlatFields.pair_bytes(nbk, nlev_t, args.nproma) + (nbk * nlev_t * args.nproma * c2.binding.REAL_BYTES + 4096 if (args.kernel == "ad" and args.levapls2) else 0)
-    ds = c2.DeviceState.from_table(tab, args.nproma, args.ngptot, dev, start=col0, reserve=reserve)
-    placement = dict(getattr(ds.arena, "info", {}))
+    ds, step, bpc, keep, kname, placement = build_step(c2, args, tab, prm, args.kernel, dev, stream, col0)
     nlev = ds.nlev
-    if args.kernel == "nl":
-        step, bpc, keep = (lambda: ds.nl(prm, stream)), c2.bytes_per_column(nlev, "nl_driver"), ds
-        kname = "nl_kernel<F> (SATUR + CLOUDSC2 fused; fast math, no evaporation branch, 32-bit offsets when buffers < 4 GiB)"
-    else:
-        ds.satur(prm, stream)
-        inc, dout = c2.FlatFields.pair(ds.nb, ds.nlev, ds.nproma, dev, arena=ds.arena)  # increments + TL outputs
-        ds.increments(zero_supsat=(args.kernel == "ad"), into=inc)
-        if args.kernel == "tl":
-            step, bpc, keep = (lambda: ds.tl(prm, inc, dout, stream)), c2.bytes_per_column(nlev, "tl"), (ds, inc, dout)
-            kname = ("tl_kernel<C2F_QSAT|C2F_TRAJ> (CLOUDSC2TL: trajectory evaluated in the sweep, its ten outputs and the ten TL outputs stored; "
-                     "launches of a few partial rounds of workgroups are paced, CLOUDSC2_PACE=0 switches that off)")
-        else:
-            ds.tl(prm, inc, dout, stream)  # leaves the trajectory outputs (PFPLSL5 / PFPLSN5) in the state
-            # the cover-checkpoint plane exists only with the evaporation branch (its one reader)
-            scratch = ds.arena.take((ds.nb, ds.nlev, ds.nproma)) if args.levapls2 else None
-            step = lambda: ds.ad(prm, inc, dout, scratch, stream, assign=args.ad_assign, sweep=args.ad_sweep)  # noqa: E731
-            bpc = c2.bytes_per_column(nlev, "ad" if args.ad_sweep == "both" else "ad_reverse")
-            if args.levapls2:  # + the checkpoint plane: written by the forward sweep, read by the reverse sweep
-                bpc += c2.bytes_per_column(nlev, "ad_ckpt") // (1 if args.ad_sweep == "both" else 2)
-            kname = ("ad_kernel<C2F_QSAT> (CLOUDSC2AD: trajectory pass + reverse pass; partial rounds paced)" if args.ad_sweep == "both" else
-                     "ad_reverse_kernel<C2F_QSAT> (reverse sweep of CLOUDSC2AD alone; carries from the state's PFPLSL5 / PFPLSN5; partial rounds paced)")
-            if args.ad_assign:  # the 16 old input adjoints (15 full-level planes + PAPH's nlev+1) are not read
-                bpc -= c2.bytes_per_column(nlev, "ad_old_adjoints")
-                kname = kname.replace("<C2F_QSAT>", "<C2F_QSAT|C2F_ASSIGN>") + " [x = A^T y: old input adjoints not read]"
-            keep = (ds, inc, dout, scratch)
 
     def barrier():
         if torch.distributed.get_backend() == "nccl":
@@ -485,28 +536,9 @@ def main():
         else:
             torch.distributed.barrier()
 
-    for _ in range(max(args.warmup, 0)):
-        step()
-    for _ in range(SETTLE_LAUNCHES):  # after an idle second the GPU needs ~15 launches (12 ms) to reach its steady time again, whatever the memory
-        # (tools/settle_series.py: 0.93 0.84 0.86 0.89 0.87 ... 0.82 ms; the same after a 2 s pause); reported as `settle_launches`,
-        # next to the W warm-up steps the caller asked for (`warmup_total` = both)
-        step()
-    torch.cuda.synchronize(dev)
+    elapsed, kms = timed_steps(torch, dev, stream, step, args.steps, args.warmup, barrier if world > 1 else None)
     if world > 1:
-        barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for a, b in ev:
-        a.record(stream)
-        step()
-        b.record(stream)
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0  # this rank's K steps, device work included; the closing barrier follows, then the MAX over ranks
-    if world > 1:
-        barrier()
         elapsed = float(c2dist.allreduce_max([elapsed], dev)[0])  # MAX over ranks (RCCL all-reduce of one double)
-    kms = np.array([a.elapsed_time(b) for a, b in ev])  # per-launch device time on the launch stream
     ms_per_step = elapsed / args.steps * 1e3
     total_cols = args.ngptot * world
     value = total_cols / (elapsed / args.steps)
@@ -532,6 +564,8 @@ def main():
                 "kernel_ms_first_tenth": float(kms[:max(1, len(kms) // 10)].mean()), "kernel_ms_last_tenth": float(kms[-max(1, len(kms) // 10):].mean()),
                 "kernel_ms_avg_per_rank": [round(x, 5) for x in k_per_rank],
                 "allocation": "first and only state of the process, from cloudsc2_device_malloc_state (placed by the library)"}
+    if args.kernel == "ad" and args.ad_sweep == "both" and not args.ad_assign and not args.levapls2:
+        roofline.update(ad_design_floor(c2, nlev, k_avg, args.ngptot))
     if world > 1:  # every rank's placement next to its kernel time (a slow rank is a slow place or a slow GPU: this tells which)
         pr = {k: c2dist.allgather_scalar(float(placement.get(k, 0.0)), dev) for k in ("candidates", "probe_ms_best", "probe_ms_median", "probe_ms_worst")}
         roofline["placement_per_rank"] = [{"rank": r, "candidates": int(pr["candidates"][r]), "probe_ms_best": pr["probe_ms_best"][r],
@@ -583,9 +617,26 @@ def main():
                               "frac_actual_bytes": d["roofline"]["frac_actual_bytes"], "traffic_source": d["roofline"].get("traffic_source"),
                               "kernel": d["roofline"]["kernel"],
                               "placement": d["config"]["placement"]}
+                for k in ("bytes_per_column_design_floor", "frac_design_floor", "design_floor"):
+                    if k in d["roofline"]:
+                        comp[kind][k] = d["roofline"][k]
             except Exception as e:  # noqa: BLE001  (never let the companions break the headline line)
                 comp[kind] = {"error": repr(e)}
         out["companion_kernels"] = comp
+        # (1b) BASELINE.json configs[1] names an NPROMA sweep 32-256: the same NL bench at the other three blockings, each in a fresh
+        # process with its own placed state (the headline's own blocking is this run's figure)
+        sweep = {str(args.nproma): {"kernel_ms_avg": k_avg, "frac": fr["frac"], "value": value, "steps": args.steps, "source": "this run (the headline)"}}
+        for npr in (32, 64, 128, 256):
+            if npr == args.nproma:
+                continue
+            try:
+                d = child_bench(["--kernel", "nl", "--steps", 100, "--warmup", 5, "--ngptot", args.ngptot, "--no-cpu-baseline", "--no-companions",
+                                 "--nproma", npr, "--precision", args.precision] + (["--levapls2"] if args.levapls2 else []))
+                sweep[str(npr)] = {"kernel_ms_avg": d["roofline"]["kernel_ms_avg"], "frac": d["roofline"]["frac"], "value": d["value"],
+                                   "steps": d["steps"], "source": "child process"}
+            except Exception as e:  # noqa: BLE001
+                sweep[str(npr)] = {"error": repr(e)}
+        out["nproma_sweep"] = dict(sorted(sweep.items(), key=lambda kv: int(kv[0])))
         # (2) north_star's target: >= 70 % of the HBM peak on the NL kernel at NGPTOT >= 1 M columns on one GPU
         try:
             d = child_bench(["--kernel", "nl", "--steps", 50, "--warmup", 5, "--ngptot", 1048576] + common)
@@ -620,13 +671,44 @@ def main():
         cb = cpu_baseline(tab, prm, 32, args.ngptot)
         if cb:
             out["cpu_baseline"] = cb
+    if world > 1 and args.kernel == "nl" and not args.no_companions:
+        # BASELINE.json configs[4] names NL + TL + AD on the node: every rank times the other two kernels IN-PROCESS on its own
+        # columns (the NL state is given back first; 160 000 columns with their perturbation sets are 17 GB of the GPU's 288), with
+        # the protocol of the headline -- barrier, K steps, barrier, MAX over ranks -- and `value` = all ranks' columns over that
+        # time.  Same NPROMA as the headline for all three kernels (128: the TL / AD optimum of the one-GPU sweep, 1 % off NL's).
+        # A failure here is recorded and does not touch the timing line that is already out.
+        comp = {}
+        try:
+            del step, keep, ds
+            torch.cuda.empty_cache()
+            for kind in ("tl", "ad"):
+                prm_k = c2.default_params(c2.ceta_from_table(tab), lregcl=(kind == "ad"), levapls2=args.levapls2)
+                ds_k, step_k, bpc_k, keep_k, kname_k, place_k = build_step(c2, args, tab, prm_k, kind, dev, stream, col0)
+                k_steps = max(5, min(args.steps, 30))
+                el_k, kms_k = timed_steps(torch, dev, stream, step_k, k_steps, min(args.warmup, 5), barrier)
+                el_k = float(c2dist.allreduce_max([el_k], dev)[0])
+                per_rank = c2dist.allgather_scalar(float(kms_k.mean()), dev)
+                worst = max(per_rank)
+                comp[kind] = {"value": args.ngptot * world / (el_k / k_steps), "unit": "columns/s", "steps": k_steps, "ms_per_step": el_k / k_steps * 1e3,
+                              "kernel_ms_avg": worst, "kernel_ms_avg_per_rank": [round(x, 5) for x in per_rank],
+                              "bytes_per_column": bpc_k, "frac": bpc_k * args.ngptot / (worst * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "frac_is": "the slowest rank's kernel against ONE GPU's HBM peak", "nproma": args.nproma, "kernel": kname_k,
+                              "candidates_per_rank": [int(x) for x in c2dist.allgather_scalar(float(place_k.get("candidates", 0)), dev)]}
+                if kind == "ad":
+                    comp[kind].update(ad_design_floor(c2, ds_k.nlev, worst, args.ngptot))
+                del step_k, keep_k, ds_k
+                torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001
+            comp["error"] = repr(e)
+        out["companion_kernels"] = comp
+        ds = step = keep = None
     native_hung = False
     if world > 1:
         # The only inter-GPU exchange of the path: max-reduce the two self-tests' verdict norms (outside the timing).  Each rank
         # runs the Taylor test and the adjoint test on its own 1024-column sub-range; ZNORMG(10) and ZNORMG are all-reduced
         # (MAX) over RCCL -- cloudsc_driver_tl_mod.F90:125, cloudsc_driver_ad_mod.F90:107 carried across ranks.
         try:
-            del step, keep, ds
+            ds = step = keep = None  # (gives the device memory back, whether or not the companions above already did)
             torch.cuda.empty_cache()
             ceta = c2.ceta_from_table(tab)
             vt = c2.state_from_table(tab, 64, 1024, col0=rank * 1024)
@@ -671,6 +753,19 @@ def main():
         except Exception as e:  # noqa: BLE001
             out["verdicts"] = {"error": repr(e)}
     if rank == 0:
+        if world > 1 and not args.no_cpu_baseline and args.kernel == "nl" and not native_hung:
+            # rank 0's host cores, after the last collective (no rank waits for it), only while the budget has room: the launcher's
+            # deadline must not take the final line with it
+            left = budgets(args.budget_s)[0] - (time.monotonic() - t_start)
+            if left > 90.0:
+                try:
+                    cb = cpu_baseline(tab, prm, 32, args.ngptot, budget_s=min(15.0, left / 6.0))
+                    if cb:
+                        out["cpu_baseline"] = cb
+                except Exception as e:  # noqa: BLE001
+                    out["cpu_baseline"] = {"error": repr(e)}
+            else:
+                out["cpu_baseline"] = {"skipped": f"{left:.0f} s of --budget-s left"}
         if world > 1:
             out["stage"] = "final"
             out["seconds_since_start"] = round(time.monotonic() - t_start, 1)

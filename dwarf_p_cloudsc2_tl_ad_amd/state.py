@@ -217,6 +217,10 @@ def _reals_per_column(nlev: int, kernel: str) -> int:
     x = half + 15 * full
     if kernel == "ad":                        # traj in (+PQS5), y in, x in (+=), y <- 0, x out, traj out
         return (nl_in + full) + nl_out + x + nl_out + x + nl_out
+    if kernel == "ad_design_floor":           # what a two-pass adjoint of a 137-level column must move: `ad` + the SECOND read of the
+        # trajectory inputs by the reverse pass (cloudsc2ad.F90:366-866 forward, :877-1740 reverse: the reference keeps the whole
+        # trajectory of a block in cache-resident arrays; at 17.5 KB per column it does not survive on chip for a CU's 256 columns)
+        return (nl_in + full) + nl_out + x + nl_out + x + nl_out + (nl_in + full)
     if kernel == "ad_reverse":                # reverse sweep alone: traj in (+PQS5), PFPLSL5/PFPLSN5 at JK, y in, x in, y <- 0, x out
         return (nl_in + full) + 2 * full + nl_out + x + nl_out + x
     if kernel == "ad_ckpt":                   # the cover-checkpoint plane, written and re-read (evaporation branch only)

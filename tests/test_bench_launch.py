@@ -117,6 +117,24 @@ def test_roofline_fractions_in_every_byte_convention():
     assert bench.roofline_fractions(1.0, 1000, 8, None, None)["frac_actual_bytes"] is None
 
 
+def test_the_adjoints_design_floor():
+    """CLOUDSC2AD moves 85 608 B per column by SURVEY 8d's count -- if the trajectory survived on chip between the forward pass
+    (cloudsc2ad.F90:366-866) and the reverse pass (:877-1740).  It cannot (17.5 KB per column), so the reverse pass reads the
+    2 193 trajectory-input doubles a second time: 103 152 B is what a two-pass adjoint must move, and the line carries the fraction
+    against that figure next to the algorithmic one.  BENCH_r04's AD: 2.8126 ms at 160 000 columns."""
+    import bench
+    import dwarf_p_cloudsc2_tl_ad_amd as c2
+
+    assert c2.bytes_per_column(137, "ad", 8) == 85608
+    assert c2.bytes_per_column(137, "ad_design_floor", 8) == 85608 + 8 * (138 + 15 * 137) == 103152
+    assert c2.bytes_per_column(137, "ad_design_floor", 4) == 103152 // 2
+    f = bench.ad_design_floor(c2, 137, 2.8126, 160000)
+    assert f["bytes_per_column_design_floor"] == c2.bytes_per_column(137, "ad_design_floor")
+    if c2.binding.REAL_BYTES == 8:
+        assert abs(f["frac_design_floor"] - 103152 * 160000 / 2.8126e-3 / 8e12) < 1e-12 and abs(f["frac_design_floor"] - 0.7335) < 5e-4
+        assert abs(bench.roofline_fractions(2.8126, 160000, 85608)["frac"] - 0.6087) < 5e-4  # the same launch against SURVEY's figure
+
+
 def test_more_ranks_than_gpus_is_refused_before_anything_starts():
     import torch
 

@@ -57,6 +57,38 @@ def test_two_ranks_on_one_gpu_rehearse_the_multi_gpu_path(tmp_path):
     assert len(d["roofline"]["kernel_ms_avg_per_rank"]) == 2
     v = d["verdicts"]
     assert v["backend"] == "gloo" and v["tl_passed"] and v["ad_ok"] and len(v["tl_znormg"]) == 10, v
+    # BASELINE configs[4] names NL + TL + AD: the N > 1 line carries the other two kernels, timed in-process on every rank with the
+    # headline's protocol, and rank 0's CPU baseline
+    ck = d["companion_kernels"]
+    assert "error" not in ck, ck
+    for kind, bpc in (("tl", 57072), ("ad", 85608)):
+        c = ck[kind]
+        assert c["bytes_per_column"] == bpc and c["unit"] == "columns/s" and c["nproma"] == 128 and c["steps"] >= 5
+        assert len(c["kernel_ms_avg_per_rank"]) == 2 and abs(c["kernel_ms_avg"] - max(c["kernel_ms_avg_per_rank"])) < 1e-5 and c["kernel_ms_avg"] > 0
+        assert abs(c["value"] - 2 * 16384 / (c["ms_per_step"] * 1e-3)) < 1e-6 * c["value"]
+        assert abs(c["frac"] - bpc * 16384 / (c["kernel_ms_avg"] * 1e-3) / 8e12) < 1e-9
+    assert ck["ad"]["bytes_per_column_design_floor"] == 103152
+    assert abs(ck["ad"]["frac_design_floor"] / ck["ad"]["frac"] - 103152 / 85608) < 1e-9
+    assert "companion_kernels" not in own[0]  # the timing line went out before them
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["value"] > 1e4 and cb["cores"] >= 1, cb
+
+
+def test_the_default_line_carries_the_nproma_sweep_and_the_adjoints_floor():
+    """BASELINE.json configs[1] names an NPROMA sweep 32-256: the driver-run line carries NL at all four blockings (children with their
+    own placed state), and the AD companion carries the design floor next to the algorithmic fraction."""
+    r = _bench(["--steps", 50, "--warmup", 3, "--no-cpu-baseline"], timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    sw = d["nproma_sweep"]
+    assert list(sw) == ["32", "64", "128", "256"], sw
+    for npr, e in sw.items():
+        assert "error" not in e and e["kernel_ms_avg"] > 0 and abs(e["frac"] - 28536 * 160000 / (e["kernel_ms_avg"] * 1e-3) / 8e12) < 1e-9, (npr, e)
+    assert sw["128"]["kernel_ms_avg"] == d["roofline"]["kernel_ms_avg"] and sw["128"]["source"].startswith("this run")
+    ad = d["companion_kernels"]["ad"]
+    assert ad["bytes_per_column"] == 85608 and ad["bytes_per_column_design_floor"] == 103152
+    assert abs(ad["frac_design_floor"] - 103152 * 160000 / (ad["kernel_ms_avg"] * 1e-3) / 8e12) < 1e-9 and ad["frac_design_floor"] > ad["frac"]
+    assert "bytes_per_column_design_floor" not in d["companion_kernels"]["tl"]
 
 
 def test_host_array_driver_rate_is_reported_beside_the_value():

@@ -1,0 +1,3 @@
+out=gpurun_out/r05_c; mkdir -p $out
+timeout -k 10 1000 python -m pytest tests/test_gpu_bench.py -m gpu -q -x > $out/pytest_bench.log 2>&1; echo "pytest rc=$?"; tail -15 $out/pytest_bench.log
+t0=$(date +%s); timeout -k 10 600 python bench.py > $out/bench_default.json 2> $out/bench_default.err; echo "bench rc=$? in $(( $(date +%s) - t0 )) s"; cut -c1-400 $out/bench_default.json
