@@ -23,6 +23,11 @@
 #include <cmath>
 #include "../../include/cloudsc2_hip.h"
 
+// -DC2_EVAP_FAST=0: the evaporation block (LEVAPLS2 / LDRAIN1D variants) keeps IEEE divisions and pow() in fast mode too (A/B builds)
+#ifndef C2_EVAP_FAST
+#define C2_EVAP_FAST 1
+#endif
+
 namespace cloudsc2 {
 
 // JPRB (src/common/module/parkind1.F90:40-44): fp64, or fp32 when the library is built with -DCLOUDSC2_SINGLE (the
@@ -740,8 +745,41 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
   t.zpreclr1 = RC(0.0); t.zqe = RC(0.0); t.zbeta = RC(0.0); t.zb = RC(0.0); t.zdtgdp = RC(1.0); t.zdpr1 = RC(0.0); t.zdpr = RC(0.0);
   t.zpreclr = RC(0.0); t.omc = RC(1.0); t.zsqp = RC(1.0);
   if (t.llo2) {
-    t.zpreclr1 = t.zprtot * t.covpclr / t.covptot1;
     t.omc = RC(1.0) - t.clc;
+#if C2_EVAP_FAST
+    if (!P) {
+      // fast arithmetic (round 5): the block's seven IEEE divisions on three refined v_rcp_f64 (1/covptot1 and 1/omc^2 from one,
+      // 1/covpclr, 1/prtot and 1/p_surf from one, 1/(1 + beta dt corqs) alone), the division by ZDTGDP = dt g / dp as a product
+      // with dp / (dt g), which the level has anyway, and x^0.5777 as exp(0.5777 ln x) on the branch-free exp -- a few ulp from
+      // the reference's order, like the rest of the fast path; the precise mode below keeps that order
+      real_t r_cov1, r_omc2, r_clr, r_prtot, r_psurf;
+      c2_rcp2(t.covptot1, t.omc * t.omc, r_cov1, r_omc2);
+      c2_rcp3(t.covpclr, t.zprtot, x.paph_surf, r_clr, r_prtot, r_psurf);
+      t.zpreclr1 = t.zprtot * t.covpclr * r_cov1;
+      t.zqe = x.qs - (x.qs - t.zqlim) * t.covpclr * r_omc2;
+      t.zsqp = sqrt(x.pap * r_psurf);
+      t.zbeta = c->rg * c->rpecons * c2_exp(RC(0.5777) * log(t.zsqp * RC(196.46365422396858) * t.zpreclr1 * r_clr));  // 1 / 5.09e-3
+      t.zb = ptsphy4 * t.zbeta * (x.qs - t.zqe) * c2_rcp(RC(1.0) + t.zbeta * ptsphy4 * t.zcorqs);
+      t.zdtgdp = c->zcons2_r * t.rdp;
+      t.zdpr1 = t.covpclr * t.zb * zcons2dp;
+      t.dpr_clip = t.zdpr1 > t.zpreclr1;
+      t.zdpr = t.dpr_clip ? t.zpreclr1 : t.zdpr1;
+      // ZPRECLR - MIN(ZDPR, ZPRECLR) is EXACTLY zero when everything evaporates, and the reset of the cover hangs on that zero
+      // (cloudsc2.F90:578-580): written as a subtraction, the contraction of zpreclr1 = (prtot covpclr) r into an fma leaves the
+      // product's rounding error (1e-25) instead and the reset is missed
+      t.zpreclr = t.dpr_clip ? RC(0.0) : t.zpreclr1 - t.zdpr1;
+      t.reset = t.zpreclr <= RC(0.0);
+      if (t.reset) covptot = t.clc;
+      pcovptot = covptot;
+      const real_t dq = t.zdpr * r_prtot;
+      t.zevapr = dq * t.rfln2;
+      t.zevaps = dq * t.sfln2;
+      rfln = rfln - t.zevapr;
+      sfln = sfln - t.zevaps;
+    } else
+#endif
+    {
+    t.zpreclr1 = t.zprtot * t.covpclr / t.covptot1;
     t.zqe = x.qs - (x.qs - t.zqlim) * t.covpclr / (t.omc * t.omc);
     t.zsqp = sqrt(x.pap / x.paph_surf);
     t.zbeta = c->rg * c->rpecons * pow(t.zsqp / RC(5.09e-3) * t.zpreclr1 / t.covpclr, RC(0.5777));
@@ -758,6 +796,7 @@ C2_HD void level_forward(ConstsP c, const LevelCst& k, const RhCrit& rh, const L
     rfln = rfln - t.zevapr;
     t.zevaps = t.zdpr * t.sfln2 / t.zprtot;
     sfln = sfln - t.zevaps;
+    }
   }
 
   // K. first-guess T and q after the cloud processes (cloudsc2.F90:602-617)
