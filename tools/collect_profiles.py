@@ -27,7 +27,7 @@ if os.path.exists(os.path.join(src, "timed_kernel_stats.csv")):  # one row per t
             shutil.copy(f, os.path.join(dst, f"{prefix}_{os.path.basename(d)[5:]}_kernel_stats.csv"))
     for f in glob.glob(os.path.join(src, "bench_prof_*_*.json")):
         name = os.path.basename(f)[len("bench_prof_"):-len(".json")]
-        if name.split("_")[0] in ("tl", "ad", "adrev", "selftests"):  # (the NL runs are copied above under their older names)
+        if name.split("_")[0] in ("tl", "ad", "adrev", "selftests", "nlevap"):  # (the NL runs are copied above under their older names)
             shutil.copy(f, os.path.join(dst, f"{prefix}_{name}_under_rocprof.json"))
 if os.path.exists(os.path.join(src, "pytest_gpu.log")):
     cp("pytest_gpu.log", "pytest_gpu.log")

@@ -7,6 +7,7 @@
 tag=${1:-ev}; stage=${2:-all}; out=gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
 if [ "$stage" != b ]; then
+du -a --max-depth=3 . 2>/dev/null | sort -n | tail -60 > $out/du_on_the_box.txt   # what travelled (.gpurunignore)
 timeout -k 10 900 python -m pytest tests -m gpu -q > $out/pytest_gpu.log 2>&1; tail -2 $out/pytest_gpu.log
 timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1 && echo smoke ok || { echo smoke FAILED; tail -5 $out/smoke.log; }
 # what the box is and how it clocks while the kernel runs (boxes of the pool measure up to 12 % apart)
@@ -25,7 +26,7 @@ python tools/trace_timed_region.py $out/prof_1m/*/*_kernel_trace.csv nl_kernel 5
 # directly after `--`, no child processes; the last K dispatches are the timed region (tools/kernel_stats_rows.py)
 specs=""
 for n in 160000 1048576; do
-  for kf in "tl:--kernel tl:tl_kernel:57072" "ad:--kernel ad:ad_kernel:85608" "adrev:--kernel ad --ad-sweep reverse --ad-assign:ad_reverse_kernel:59264"; do
+  for kf in "tl:--kernel tl:tl_kernel:57072" "ad:--kernel ad:ad_kernel:85608" "adrev:--kernel ad --ad-sweep reverse --ad-assign:ad_reverse_kernel:59264" "nlevap:--kernel nl --levapls2:nl_kernel:28536"; do
     lab=${kf%%:*}; rest=${kf#*:}; flags=${rest%%:*}; rest=${rest#*:}; pat=${rest%%:*}; bpc=${rest#*:}
     timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_${lab}_$n -- python3 bench.py $flags --ngptot $n --steps 30 --warmup 3 --no-cpu-baseline --no-companions > $out/bench_prof_${lab}_$n.json 2> $out/bench_prof_${lab}_$n.err || exit 1
     specs="$specs ${lab}_$n:$(ls $out/prof_${lab}_$n/*/*_kernel_trace.csv):$pat:30:$n:$bpc"
