@@ -729,6 +729,8 @@ std::vector<int> paced_kernel_occupancies() {
 
 // The synchronous moment.  Idempotent and cheap after the first call on a device (one mutex, one table lookup).
 int device_prepare() {
+  static std::mutex one_at_a_time;  // (two threads probing one device at once would disturb each other's placement)
+  std::lock_guard<std::mutex> serial(one_at_a_time);
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
     (void)hipGetLastError();
