@@ -488,29 +488,39 @@ int check_geom(const cloudsc2_params* prm, int nproma, int nlev, int ngptot, Geo
   return 0;
 }
 
-// Should the waves of this NL launch yield to each other by progress (cloudsc2_column.hpp: progress_priority)?  Yes when the launch
-// is ONE round of waves: no more waves than the device holds at the NL kernel's three per SIMD.  Measured
+// Workgroups per CU of one kernel on one device, as the runtime reports them (asked once per kernel and device; no device work)
+int kernel_workgroups_per_cu(const void* fn, int dev) {
+  static std::mutex mu;
+  static std::vector<std::tuple<const void*, int, int>> cache;
+  std::lock_guard<std::mutex> lock(mu);
+  for (auto& e : cache)
+    if (std::get<0>(e) == fn && std::get<1>(e) == dev) return std::get<2>(e);
+  int per_cu = 0;
+  if (!fn || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, 0) != hipSuccess || per_cu <= 0) { (void)hipGetLastError(); return 0; }
+  cache.emplace_back(fn, dev, per_cu);
+  return per_cu;
+}
+
+// Should the waves of this launch yield to each other by progress (cloudsc2_column.hpp: progress_priority)?  Yes when the launch
+// is ONE round of waves of a kernel that runs several waves per SIMD: no more workgroups than the device holds at THIS variant's own
+// occupancy (asked of the runtime: the plain and, since their block runs in fast arithmetic, the evaporation NL variants hold six
+// workgroups = three waves per SIMD; a variant that holds one wave per SIMD has nothing to keep abreast).  Measured
 // (profiles/r03_wave_times.txt): 100 000 ... 190 000 columns -1 ... -4 % (160 000: 0.815 -> 0.783 ms), 65 536 -3 %, 196 608
-// (exactly 3 per SIMD) +-1 %; with more than one round the age order is better (262 144 columns +4 %, 1 M +2 %): off there.
+// (exactly 3 per SIMD) +-1 %; the evaporation variant 160 000: 0.842 -> 0.785 ms, 100 000 -3 %, 65 536 -5 % (profiles/r05_evap_fast_ab.txt);
+// with more than one round the age order is better (262 144 columns +4 %, 1 M +2 %): off there.
 // CLOUDSC2_FAIR=0|1 forces it (measurements only).
-int nl_fair(long long ncols_pad, bool evap) {
-  (void)evap;  // (the evaporation variants run two or three waves per SIMD as well)
+int nl_fair(long long ncols_pad, const void* fn) {
   static const char* e = getenv("CLOUDSC2_FAIR");
   if (e && *e) return atoi(e) != 0;
-  // SIMDs of the CURRENT device (a process may drive several GPUs, or change device between calls): cached per device id
-  constexpr int kMaxDev = 64;
-  static std::atomic<int> simds_of[kMaxDev];  // 0 = not asked yet (zero-initialised)
-  int dev = 0, simds = 0;
-  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = -1; }
-  if (dev >= 0 && dev < kMaxDev) simds = simds_of[dev].load(std::memory_order_relaxed);
-  if (!simds) {
-    int cus = 0;
-    if (dev >= 0 && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) simds = 4 * cus;
-    else { (void)hipGetLastError(); simds = 1024; }
-    if (dev >= 0 && dev < kMaxDev) simds_of[dev].store(simds, std::memory_order_relaxed);
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+    (void)hipGetLastError();
+    return 0;
   }
-  const long long waves = (ncols_pad + 63) / 64, slots = 3LL * simds;
-  return waves <= slots;
+  const int per_cu = kernel_workgroups_per_cu(fn, dev);
+  if (per_cu < 4) return 0;  // fewer than two waves per SIMD
+  const long long wgs = (ncols_pad + kBlock - 1) / kBlock;
+  return wgs <= (long long)per_cu * cus;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -843,18 +853,7 @@ void nl_light_nap(Geom& g, KernelFn<NlArgs> fn) {
     (void)hipGetLastError();
     return;
   }
-  static std::mutex mu;
-  static std::vector<std::tuple<const void*, int, int>> cache;  // (kernel, device) -> workgroups per CU
-  int per_cu = 0;
-  {
-    std::lock_guard<std::mutex> lock(mu);
-    for (auto& e : cache)
-      if (std::get<0>(e) == (const void*)fn && std::get<1>(e) == dev) per_cu = std::get<2>(e);
-    if (!per_cu) {
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)fn, kBlock, 0) != hipSuccess || per_cu <= 0) { (void)hipGetLastError(); return; }
-      cache.emplace_back((const void*)fn, dev, per_cu);
-    }
-  }
+  const int per_cu = kernel_workgroups_per_cu((const void*)fn, dev);
   const long long wgs = (g.ncols_pad + kBlock - 1) / kBlock;
   if (per_cu != 6 || wgs > (long long)cus * per_cu) return;
   const long long q = wgs / cus, r = wgs % cus, fullest = q + (r ? 1 : 0);
@@ -1099,7 +1098,7 @@ int cloudsc2_nl_launch(const cloudsc2_params* prm, double ptsphy, int nproma, in
   if ((f & C2F_NOLIN) && (f & C2F_PERT))
     return fail(CLOUDSC2_EINVAL, "pert_lambda != 0 with LPHYLIN = 0: the perturbed runs of the Taylor test exist in the LPHYLIN form only");
   if (fits_off32(g, nproma, nlev, {s.full, s.half, s.cml, s.clv, s.loc, (long long)zero_plane.block_stride})) f |= C2F_OFF32;
-  args.g.fair = nl_fair(g.ncols_pad, args.c.evap != 0);
+  args.g.fair = nl_fair(g.ncols_pad, (const void*)nl_variant(f));
   nl_light_nap(args.g, nl_variant(f));
   return launch_variant(nl_variant(f), args, g.ncols_pad, (hipStream_t)stream);
 }
@@ -1149,7 +1148,7 @@ static int tl_launch_impl(const cloudsc2_params* prm, double ptsphy, int nproma,
   // the fp32 TL variants that run three waves per SIMD (tl_kernel's launch bounds) share their SIMDs like the NL kernel does:
   // -3.7 % at 160 000 columns with the waves kept abreast; the fp64 TL and both adjoints run one wave per SIMD and lose 1-5 %
   // (profiles/r03_wave_times.txt)
-  if (sizeof(real_t) == 4 && (f & C2F_OFF32) && !(f & C2F_EVAP)) args.g.fair = nl_fair(g.ncols_pad, false);
+  if (sizeof(real_t) == 4 && (f & C2F_OFF32) && !(f & C2F_EVAP)) args.g.fair = nl_fair(g.ncols_pad, (const void*)tl_variant(f));
   else set_pace(args.g, tl_variant(f));
   return launch_variant(tl_variant(f), args, g.ncols_pad, (hipStream_t)stream);
 }
@@ -1217,7 +1216,7 @@ static int ad_launch_impl(const cloudsc2_params* prm, double ptsphy, int nproma,
   // as a kernel of its own the trajectory pass is the NL kernel at its three waves per SIMD: keep them abreast like cloudsc2_nl_launch
   // does (inside the fused kernel, one wave per SIMD, the priority code is compiled out)
   const bool fused = which == 0 && (C2_AD_FUSED == 1 || (C2_AD_FUSED == 2 && g.ncols_pad > kAdSplitBelow));
-  if (!fused && which != 2) args.nl.g.fair = nl_fair(g.ncols_pad, args.nl.c.evap != 0);
+  if (!fused && which != 2) args.nl.g.fair = nl_fair(g.ncols_pad, (const void*)nl_variant(f_fwd));
   if (which == 1) return launch_variant(nl_variant(f_fwd), args.nl, g.ncols_pad, (hipStream_t)stream);
   set_pace(args.nl.g, (which == 2 || !fused) ? ad_reverse_variant(f) : ad_variant(f));
   if (which == 2) return launch_variant(ad_reverse_variant(f), args, g.ncols_pad, (hipStream_t)stream);
