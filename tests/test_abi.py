@@ -206,3 +206,28 @@ def test_the_simd_population_rule_of_one_round_launches():
     heavy = sum(pop(b, w)[0] == 3 for b in range(1250) for w in (0, 1))
     assert heavy == 1356  # = 452 SIMDs x 3 waves (profiles/r03_wave_times.txt)
     assert B.lib.cloudsc2_simd_population(1250, 256, 1250, 0, C.byref(C.c_int()), C.byref(C.c_int())) != 0
+
+
+def test_the_synthetic_table_has_one_implementation():
+    """cloudsc2_synthetic_table (host code in the library) is what every front end loads when input.h5 is absent: the Python side
+    returns its arrays unchanged, the recipe's invariants hold, and the numpy-flavoured fixture (rounds 1-4's table, on which the
+    reference's Taylor test fails at NPROMA 32: tests/golden/drivers.json) differs from it in the last place only."""
+    import json
+
+    tab = c2.synthetic_table()
+    names = ("PT", "PQ", "PAP", "PAPH", "PLU", "PLUDE", "PMFU", "PMFD", "PCLV_QL", "PCLV_QI", "TENDENCY_CML_T", "TENDENCY_CML_Q")
+    arr = {n: np.zeros((137 + (n == "PAPH"), 100)) for n in names}
+    dp = C.POINTER(C.c_double)
+    B.check(B.lib.cloudsc2_synthetic_table(100, 137, 287.0597, 461.5250, 273.16, *[arr[n].ctypes.data_as(dp) for n in names]))
+    for n in names:
+        assert np.array_equal(tab[n], arr[n]), n
+    assert np.all(np.diff(tab["PAPH"], axis=0) > 0) and np.allclose(tab["PAP"], 0.5 * (tab["PAPH"][:-1] + tab["PAPH"][1:]), rtol=1e-15)
+    assert tab["PT"].min() >= 205.0 and tab["PQ"].min() > 0 and np.all(tab["PCLV_QL"] > 0) and np.all(tab["PCLV_QI"] >= 0)
+    assert np.any(tab["PLU"] > 0) and np.all(tab["PMFD"] <= 0) and not np.any(tab["PA"]) and not np.any(tab["PSUPSAT"])
+    assert B.lib.cloudsc2_synthetic_table(0, 137, 287.0597, 461.5250, 273.16, *[arr[n].ctypes.data_as(dp) for n in names]) != 0
+    z = np.load(os.path.join(ROOT, "tests", "golden", "table_numpy.npz"))
+    meta = json.load(open(os.path.join(ROOT, "tests", "golden", "drivers.json")))["fixtures"]["table_numpy"]
+    assert sorted(z.files) == sorted(meta["fields_that_differ_from_cloudsc2_synthetic_table"]) and "PQ" in z.files
+    for n in z.files:
+        rel = np.max(np.abs(z[n] - tab[n]) / np.abs(tab[n]))
+        assert 0.0 < rel < 2e-14, (n, rel)
