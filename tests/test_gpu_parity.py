@@ -437,15 +437,25 @@ def test_full_size_periodicity_and_determinism():
             base = {n: a.transpose(0, 2, 1).reshape(-1, a.shape[1])[:100].copy() for n, a in got.outputs().items()}
 
 
-def test_full_size_tl_ad_properties():
-    """BASELINE size (NGPTOT=160000) for the TL and the AD kernels through size-independent properties:
-    periodicity (column g == column g mod 100, bit for bit), linearity of the TL in dx, and the adjoint identity
-    <TL dx, TL dx> = <dx, AD(TL dx)> summed per column (the reference's own test, cloudsc_driver_ad_mod.F90:184-264)."""
+def _periodic(c, ngptot):
+    """column g == column g mod 100, bit for bit, for ALL columns of a (column, level) tensor (any NGPTOT)"""
+    import torch
+
+    if ngptot % 100 == 0:
+        return torch.equal(c.reshape(-1, 100, c.shape[1]), c[:100].expand(ngptot // 100, 100, c.shape[1]))
+    idx = torch.arange(ngptot, device=c.device) % 100
+    return torch.equal(c, c[:100][idx])
+
+
+def _full_size_tl_ad(ngptot, linearity):
+    """The TL and the AD kernels at a full size through size-independent properties -- periodicity (column g == column g mod 100,
+    bit for bit), linearity of the TL in dx, the adjoint identity <TL dx, TL dx> = <dx, AD(TL dx)> per column (the reference's own
+    test, cloudsc_driver_ad_mod.F90:184-264) -- AND directly against CLOUDSC2TL / CLOUDSC2AD for a sample of blocks."""
     import torch
 
     tab = c2.synthetic_table()
     prm = c2.default_params(c2.ceta_from_table(tab), lregcl=True)
-    nproma, ngptot = 128, 160000
+    nproma = 128
     ds = c2.DeviceState.from_table(tab, nproma, ngptot)
     ds.satur(prm)
     dx = ds.increments(zero_supsat=True)
@@ -458,20 +468,20 @@ def test_full_size_tl_ad_properties():
 
     # periodicity of the TL outputs
     for n, t in dy.t.items():
-        c = columns(t)
-        assert torch.equal(c.reshape(-1, 100, c.shape[1]), c[:100].expand(ngptot // 100, 100, c.shape[1])), n
-    # linearity: TL(2 dx) == 2 TL(dx) (scaling by a power of two is exact in every product and sum)
-    dx2 = c2.FlatFields("in", ds.nb, ds.nlev, ds.nproma, ds.device)
-    for n in dx.t:
-        torch.mul(dx.t[n], 2.0, out=dx2.t[n])
-    dy2 = c2.FlatFields("out", ds.nb, ds.nlev, ds.nproma, ds.device)
-    ds.tl(prm, dx2, dy2)
-    torch.cuda.synchronize()
-    for n in dy.t:
-        assert torch.equal(dy2.t[n], 2.0 * dy.t[n]), n
+        assert _periodic(columns(t), ngptot), n
+    if linearity:  # TL(2 dx) == 2 TL(dx) (scaling by a power of two is exact in every product and sum)
+        dx2 = c2.FlatFields("in", ds.nb, ds.nlev, ds.nproma, ds.device)
+        for n in dx.t:
+            torch.mul(dx.t[n], 2.0, out=dx2.t[n])
+        dy2 = c2.FlatFields("out", ds.nb, ds.nlev, ds.nproma, ds.device)
+        ds.tl(prm, dx2, dy2)
+        torch.cuda.synchronize()
+        for n in dy.t:
+            assert torch.equal(dy2.t[n], 2.0 * dy.t[n]), n
+        del dx2, dy2
     # adjoint identity per column; the AD consumes (zeroes) its output adjoints and accumulates into zeroed input adjoints
     norm1 = sum((columns(t) ** 2).sum(dim=1) for t in dy.t.values())
-    sample = (0, 1, 625, ds.nb - 1)  # blocks compared DIRECTLY with the checker below (block 0 alone holds all 100 distinct columns)
+    sample = (0, 1, ds.nb // 2, ds.nb - 1)  # blocks compared DIRECTLY with the checker below (block 0 alone holds all 100 distinct columns)
     tl_dev = {ibl: {n: t[ibl].cpu().numpy() for n, t in dy.t.items()} for ibl in sample}
     xa = c2.FlatFields("in", ds.nb, ds.nlev, ds.nproma, ds.device)
     scratch = ds.new_scratch()
@@ -484,31 +494,90 @@ def test_full_size_tl_ad_properties():
     assert err < 1e4, err          # the reference's threshold (cloudsc_driver_ad_mod.F90:289)
     assert err * np.finfo(np.float64).eps < 1e-12, err  # BASELINE configs[3]: to 1e-12
     for n, t in xa.t.items():
-        c = columns(t)
-        assert torch.equal(c.reshape(-1, 100, c.shape[1]), c[:100].expand(ngptot // 100, 100, c.shape[1])), n
+        assert _periodic(columns(t), ngptot), n
 
-    # The same 160 000-column launches against CLOUDSC2TL / CLOUDSC2AD themselves (cloudsc2tl.F90:10-24, cloudsc2ad.F90:10-24),
-    # block by block for a sample of blocks: every TL output and every input adjoint of every column of those blocks.  Together
-    # with the bit-periodicity asserted above (column g == column g mod 100 for ALL 160 000 columns of every TL output and every
-    # input adjoint, and block 0 holds columns 0..99) this is the oracle comparison of the metric's exact size, not a property.
+    # The same launches against CLOUDSC2TL / CLOUDSC2AD themselves (cloudsc2tl.F90:10-24, cloudsc2ad.F90:10-24), block by block
+    # for a sample of blocks: every TL output and every input adjoint of every column of those blocks.  Together with the
+    # bit-periodicity asserted above (column g == column g mod 100 for ALL columns of every TL output and every input adjoint, and
+    # block 0 holds columns 0..99) this is the oracle comparison of the exact size, not a property.
     chk = checker()
     set_lib_params(chk, prm)
     worst_tl = worst_ad = 0.0
     for ibl in sample:
+        ncol = min(nproma, ngptot - ibl * nproma)
         stb = c2.state_from_table(tab, nproma, nproma, col0=ibl * nproma)  # the host copy of this block's inputs
         qs = ref_qsat(chk, stb)[0]
         dinp = {n: np.ascontiguousarray(t[ibl].cpu().numpy()) for n, t in dx.t.items()}
-        o5, do = chk.cloudsc2tl(stb.ptsphy, refcall.block_inputs(stb, 0, qs), dinp, kfdia=nproma, ldrain1d=False)
+        o5, do = chk.cloudsc2tl(stb.ptsphy, refcall.block_inputs(stb, 0, qs), dinp, kfdia=ncol, ldrain1d=False)
         for n in do:
-            worst_tl = max(worst_tl, relerr(do[n], tl_dev[ibl][n]))
+            worst_tl = max(worst_tl, relerr(do[n][:, :ncol], tl_dev[ibl][n][:, :ncol]))
         ain = {n: np.zeros_like(a) for n, a in dinp.items()}
         aout = {n: a.copy() for n, a in do.items()}
-        chk.cloudsc2ad(stb.ptsphy, refcall.block_inputs(stb, 0, qs), ain, aout, kfdia=nproma, ldrain1d=False)
+        chk.cloudsc2ad(stb.ptsphy, refcall.block_inputs(stb, 0, qs), ain, aout, kfdia=ncol, ldrain1d=False)
         for n in ain:
             got = xa.t[n][ibl].cpu().numpy()
-            worst_ad = max(worst_ad, np.abs(got - ain[n]).max() / max(np.abs(ain[n]).max(), 1e-300))
-    print(f"160 000 columns, blocks {sample} against CLOUDSC2TL / CLOUDSC2AD: worst TL {worst_tl:.1e}, worst AD {worst_ad:.1e}")
+            worst_ad = max(worst_ad, np.abs(got - ain[n])[:, :ncol].max() / max(np.abs(ain[n]).max(), 1e-300))
+    print(f"{ngptot} columns, blocks {sample} against CLOUDSC2TL / CLOUDSC2AD: worst TL {worst_tl:.1e}, worst AD {worst_ad:.1e}; adjoint identity {err:.1f} eps")
     assert worst_tl <= TLAD_TOL and worst_ad <= TLAD_TOL, (worst_tl, worst_ad)
+
+
+def test_full_size_tl_ad_properties():
+    """BASELINE size (NGPTOT = 160 000)."""
+    _full_size_tl_ad(160000, linearity=True)
+
+
+def test_target_size_one_million_columns():
+    """north_star's target size -- NL >= 70 % of the HBM peak at NGPTOT >= 1 M columns *with the TL Taylor and AD symmetry tests passing
+    on the GPU* -- is the one the bench times without looking at the results: 1 048 576 columns x NPROMA 128 is a 41 GB state, every
+    sweep runs its 64-bit-offset variant (the arrays pass 4 GiB) and the block index passes 8191.  Here the results: NL bit-periodic
+    over ALL columns and equal to the reference's SATUR + CLOUDSC2 on blocks 0, 1, 4096, 8191; TL and AD the same against CLOUDSC2TL /
+    CLOUDSC2AD, the adjoint identity per column; and the two self-tests on a resident state of that size with the verdicts the
+    reference prints for the full set of distinct blocks (tests/golden/drivers.json, NPROMA 128 x 3200 columns)."""
+    import json
+
+    import torch
+
+    from tests.util import ROOT
+
+    ngptot, nproma = 1048576, 128
+    tab = c2.synthetic_table()
+    prm = c2.default_params(c2.ceta_from_table(tab))
+    ds = c2.DeviceState.from_table(tab, nproma, ngptot)
+    assert ds.B_LOC.numel() * ds.B_LOC.element_size() > (1 << 32)  # past 32-bit byte offsets
+    ds.nl(prm)
+    torch.cuda.synchronize()
+    outs = {"B_LOC_T": ds.B_LOC[:, 0], "B_LOC_Q": ds.B_LOC[:, 2], "B_LOC_QL": ds.B_LOC[:, 3], "B_LOC_QI": ds.B_LOC[:, 4], "PA": ds.PA,
+            "PCOVPTOT": ds.PCOVPTOT, "PFPLSL": ds.PFPLSL, "PFPLSN": ds.PFPLSN, "PFHPSL": ds.PFHPSL, "PFHPSN": ds.PFHPSN}
+    for n, t in outs.items():
+        assert _periodic(t.permute(0, 2, 1).reshape(-1, t.shape[1])[:ngptot], ngptot), n
+    assert not ds.B_LOC[:, 7].any()  # the driver's CLD(:,:,NCLV) = 0 plane
+    chk = checker()
+    set_lib_params(chk, prm)
+    names = {"tent": "B_LOC_T", "tenq": "B_LOC_Q", "tenl": "B_LOC_QL", "teni": "B_LOC_QI", "clc": "PA", "covptot": "PCOVPTOT",
+             "fplsl": "PFPLSL", "fplsn": "PFPLSN", "fhpsl": "PFHPSL", "fhpsn": "PFHPSN"}
+    worst = 0.0
+    for ibl in (0, 1, ds.nb // 2, ds.nb - 1):
+        stb = c2.state_from_table(tab, nproma, nproma, col0=ibl * nproma)
+        qs = chk.satur(np.ascontiguousarray(stb.PAP[0]), np.ascontiguousarray(stb.PT[0]), kfdia=nproma)
+        ref = chk.cloudsc2(stb.ptsphy, refcall.block_inputs(stb, 0, qs), kfdia=nproma)
+        for rn, dn in names.items():
+            worst = max(worst, relerr(ref[rn], outs[dn][ibl].cpu().numpy()))
+    print(f"1 048 576 columns, NL blocks 0, 1, {ds.nb // 2}, {ds.nb - 1} against SATUR + CLOUDSC2: worst {worst:.1e}")
+    assert worst <= NL_TOL, worst
+    del ds, outs
+    torch.cuda.empty_cache()
+    _full_size_tl_ad(ngptot, linearity=False)
+    torch.cuda.empty_cache()
+    # the two self-tests at that size, on a resident state
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "drivers.json")))["drivers"]
+    rs = c2.ResidentState.from_table(tab, nproma, ngptot)
+    zn, ok, itest, ms_t = rs.tl_taylor(c2.default_params(c2.ceta_from_table(tab), lregcl=False))
+    ref = gold["tl_nproma128_ngptot3200"]
+    assert np.allclose(zn[:6], ref["znormg"][:6], rtol=1e-6, atol=0), (zn, ref["znormg"])
+    assert ok and ref["verdict"].startswith("TEST PASSED") and ref["verdict"].endswith(str(itest)), (ok, itest, ref["verdict"])
+    zad, ok_ad, ms_a = rs.ad_symmetry(c2.default_params(c2.ceta_from_table(tab), lregcl=True))
+    assert ok_ad and zad * np.finfo(np.float64).eps < 1e-12, zad
+    print(f"1 048 576 columns resident: Taylor test passed (penalty {itest}, {ms_t:.1f} ms), adjoint test {zad:.1f} eps ({ms_a:.1f} ms)")
 
 
 @pytest.mark.parametrize("nproma", [32, 64, 128, 256])
