@@ -1,3 +1,4 @@
+# one gpurun call of round 5 (kept as the record of what produced gpurun_out/r05_a and the profiles/r05_* files derived from it)
 out=gpurun_out/r05_a; mkdir -p $out
 CLOUDSC2_PACE_VERBOSE=1 timeout -k 10 120 python tools/capture_probe.py cold > $out/capture_cold.log 2>&1; echo "cold rc=$?" 
 CLOUDSC2_PACE_VERBOSE=1 timeout -k 10 120 python tools/capture_probe.py warm > $out/capture_warm.log 2>&1; echo "warm rc=$?"
