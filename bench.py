@@ -21,7 +21,8 @@ The line also carries `cpu_baseline` (the reference on rank 0's host cores) and,
 after the measurement: `companion_kernels` (the same bench for TL and AD -- BASELINE.json's metric names all three; AD with its
 design floor, ad_design_floor), `nproma_sweep` (NL at NPROMA 32 / 64 / 128 / 256, BASELINE configs[1]), `target_config` (NL at
 1 048 576 columns, north_star's target), `host_array_driver` (the PCIe-inclusive rate of the reference-signature path, never `value`)
-and `self_tests` (the Taylor test and the adjoint test on a resident state of the same size: verdicts and kernel time).  At N > 1
+`self_tests` (the Taylor test and the adjoint test on a resident state of the same size: verdicts and kernel time) and
+`baseline_configs_2_3` (BASELINE configs[2] and [3] at their own sizes: the Taylor test at 100 columns, the adjoint test at 16 384).  At N > 1
 (BASELINE configs[4]: NL + TL + AD on the node) `companion_kernels` comes from every rank timing TL and AD IN-PROCESS on its own
 columns after the timing line is out -- same protocol, value = all ranks' columns over the MAX-over-ranks time, per-rank kernel times
 -- and `cpu_baseline` from rank 0 after the last collective, while --budget-s has room.  None of this is inside the timed region.
@@ -667,6 +668,20 @@ def main():
             out["self_tests"] = child_bench(["--self-tests", "--ngptot", args.ngptot, "--nproma", args.nproma, "--precision", args.precision])
         except Exception as e:  # noqa: BLE001
             out["self_tests"] = {"error": repr(e)}
+        # (5) BASELINE.json configs[2] and configs[3] at their own sizes: the Taylor test at NGPTOT = 100 (the reference README's
+        # `dwarf-cloudsc2-tl 1 100 1`) and the adjoint test at NGPTOT = 16 384, identity to 1e-12
+        bc = {}
+        try:
+            d = child_bench(["--self-tests", "--ngptot", 100, "--nproma", 1, "--precision", args.precision])
+            bc["configs[2] Taylor test, NGPTOT=100, NPROMA=1"] = d["taylor_test"]
+            d = child_bench(["--self-tests", "--ngptot", 16384, "--nproma", args.nproma, "--precision", args.precision])
+            a = d["adjoint_test"]
+            a["identity_relative"] = a["znormg_in_eps"] * 2.220446049250313e-16
+            a["to_1e-12"] = bool(a["identity_relative"] < 1e-12)
+            bc[f"configs[3] adjoint test, NGPTOT=16384, NPROMA={args.nproma}"] = a
+        except Exception as e:  # noqa: BLE001
+            bc["error"] = repr(e)
+        out["baseline_configs_2_3"] = bc
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.kernel == "nl":
         cb = cpu_baseline(tab, prm, 32, args.ngptot)
         if cb:

@@ -89,6 +89,13 @@ def test_the_default_line_carries_the_nproma_sweep_and_the_adjoints_floor():
     assert ad["bytes_per_column"] == 85608 and ad["bytes_per_column_design_floor"] == 103152
     assert abs(ad["frac_design_floor"] - 103152 * 160000 / (ad["kernel_ms_avg"] * 1e-3) / 8e12) < 1e-9 and ad["frac_design_floor"] > ad["frac"]
     assert "bytes_per_column_design_floor" not in d["companion_kernels"]["tl"]
+    # BASELINE configs[2] and [3] at their own sizes, in the same line
+    bc = d["baseline_configs_2_3"]
+    assert "error" not in bc, bc
+    t = bc["configs[2] Taylor test, NGPTOT=100, NPROMA=1"]
+    a = bc["configs[3] adjoint test, NGPTOT=16384, NPROMA=128"]
+    assert t["passed"] and len(t["ratios"]) == 10 and abs(t["ratios"][5] - 1.0) < 1e-4 and t["kernel_ms"] > 0
+    assert a["passed"] and a["to_1e-12"] and a["identity_relative"] < 1e-12
 
 
 def test_host_array_driver_rate_is_reported_beside_the_value():
