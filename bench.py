@@ -350,11 +350,11 @@ def ad_design_floor(c2, nlev, kernel_ms, ngptot, peak_gbs=HBM_PEAK_GBS):
     CU's 256 resident columns would need 4.5 MB of the 160 KiB LDS.  What a two-pass adjoint must move is therefore 85 608 + the
     second read of the 2 193 trajectory-input doubles = 103 152 B per column (the PMC counters see 1.198 x 85 608 = 102.6 KB), and
     the fraction of the peak against THAT figure is what the kernel can be held to.  Pure arithmetic (tests/test_bench_launch.py)."""
-    floor = c2.bytes_per_column(nlev, "ad_design_floor")
+    floor, algo = c2.bytes_per_column(nlev, "ad_design_floor"), c2.bytes_per_column(nlev, "ad")
     return {"bytes_per_column_design_floor": int(floor),
             "frac_design_floor": floor * ngptot / (kernel_ms * 1e-3) / 1e9 / peak_gbs,
-            "design_floor": "85 608 B (SURVEY 8d) + the reverse pass's second read of the 2 193 trajectory-input doubles: a 137-level "
-                            "trajectory does not survive on chip between the two passes (cloudsc2ad.F90:366-866, :877-1740)"}
+            "design_floor": f"{algo} B (SURVEY 8d's count) + the reverse pass's second read of the {(nlev + 1) + 15 * nlev} trajectory-input values: a "
+                            f"{nlev}-level trajectory does not survive on chip between the two passes (cloudsc2ad.F90:366-866, :877-1740)"}
 
 
 def timed_steps(torch, dev, stream, step, steps, warmup, barrier=None):
