@@ -344,13 +344,15 @@ def build_step(c2, args, tab, prm, kernel, dev, stream, col0):
     return ds, step, bpc, keep, kname, placement
 
 
-def ad_design_floor(c2, nlev, kernel_ms, ngptot, peak_gbs=HBM_PEAK_GBS):
+def ad_design_floor(c2, nlev, kernel_ms, ngptot, peak_gbs=HBM_PEAK_GBS, evap=False):
     """CLOUDSC2AD, both sweeps, accumulate form: SURVEY 8d's 85 608 B per column assume the trajectory survives on chip between the
     forward pass (cloudsc2ad.F90:366-866) and the reverse pass (:877-1740).  A 137-level column's trajectory inputs are 17 544 B; a
     CU's 256 resident columns would need 4.5 MB of the 160 KiB LDS.  What a two-pass adjoint must move is therefore 85 608 + the
     second read of the 2 193 trajectory-input doubles = 103 152 B per column (the PMC counters see 1.198 x 85 608 = 102.6 KB), and
     the fraction of the peak against THAT figure is what the kernel can be held to.  Pure arithmetic (tests/test_bench_launch.py)."""
     floor, algo = c2.bytes_per_column(nlev, "ad_design_floor"), c2.bytes_per_column(nlev, "ad")
+    if evap:  # + the cover-checkpoint plane the evaporation branch writes in the forward pass and reads in the reverse pass
+        floor, algo = floor + c2.bytes_per_column(nlev, "ad_ckpt"), algo + c2.bytes_per_column(nlev, "ad_ckpt")
     return {"bytes_per_column_design_floor": int(floor),
             "frac_design_floor": floor * ngptot / (kernel_ms * 1e-3) / 1e9 / peak_gbs,
             "design_floor": f"{algo} B (SURVEY 8d's count) + the reverse pass's second read of the {(nlev + 1) + 15 * nlev} trajectory-input values: a "
@@ -565,8 +567,8 @@ def main():
                 "kernel_ms_first_tenth": float(kms[:max(1, len(kms) // 10)].mean()), "kernel_ms_last_tenth": float(kms[-max(1, len(kms) // 10):].mean()),
                 "kernel_ms_avg_per_rank": [round(x, 5) for x in k_per_rank],
                 "allocation": "first and only state of the process, from cloudsc2_device_malloc_state (placed by the library)"}
-    if args.kernel == "ad" and args.ad_sweep == "both" and not args.ad_assign and not args.levapls2:
-        roofline.update(ad_design_floor(c2, nlev, k_avg, args.ngptot))
+    if args.kernel == "ad" and args.ad_sweep == "both" and not args.ad_assign:
+        roofline.update(ad_design_floor(c2, nlev, k_avg, args.ngptot, evap=args.levapls2))
     if world > 1:  # every rank's placement next to its kernel time (a slow rank is a slow place or a slow GPU: this tells which)
         pr = {k: c2dist.allgather_scalar(float(placement.get(k, 0.0)), dev) for k in ("candidates", "probe_ms_best", "probe_ms_median", "probe_ms_worst")}
         roofline["placement_per_rank"] = [{"rank": r, "candidates": int(pr["candidates"][r]), "probe_ms_best": pr["probe_ms_best"][r],
@@ -710,7 +712,7 @@ def main():
                               "frac_is": "the slowest rank's kernel against ONE GPU's HBM peak", "nproma": args.nproma, "kernel": kname_k,
                               "candidates_per_rank": [int(x) for x in c2dist.allgather_scalar(float(place_k.get("candidates", 0)), dev)]}
                 if kind == "ad":
-                    comp[kind].update(ad_design_floor(c2, ds_k.nlev, worst, args.ngptot))
+                    comp[kind].update(ad_design_floor(c2, ds_k.nlev, worst, args.ngptot, evap=args.levapls2))
                 del step_k, keep_k, ds_k
                 torch.cuda.empty_cache()
         except Exception as e:  # noqa: BLE001

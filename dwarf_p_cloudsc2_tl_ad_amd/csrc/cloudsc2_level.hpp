@@ -27,6 +27,10 @@
 #ifndef C2_EVAP_FAST
 #define C2_EVAP_FAST 1
 #endif
+// -DC2_EVAP_FAST_TLAD=0: only the tangent / adjoint blocks of level_tl / level_ad keep their divisions, pow() and sqrt() (A/B builds)
+#ifndef C2_EVAP_FAST_TLAD
+#define C2_EVAP_FAST_TLAD C2_EVAP_FAST
+#endif
 
 namespace cloudsc2 {
 
@@ -1055,6 +1059,33 @@ C2_HD void level_tl(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
   real_t zevapr = RC(0.0), zevaps = RC(0.0), pcovptot = RC(0.0);
   if (t.llo2) {
     real_t zprtot = zrfln + zsfln;
+#if C2_EVAP_FAST_TLAD
+    // The block's seventeen divisions, its pow() and its sqrt() on six reciprocals (two refined v_rcp_f64), and the tangent of
+    // ZBETA = RG RPECONS (B / 5.09e-3)^0.5777, B = sqrt(p / p_surf) ZPRECLR / ZCOVPCLR, as 0.5777 ZBETA5 dB / B with
+    //   dB / B = dZPRECLR / ZPRECLR5 + dp / (2 p) - dp_surf / (2 p_surf) - dZCOVPCLR / ZCOVPCLR5
+    // -- the same linear map as cloudsc2tl.F90:871-882, with the power and the root cancelled instead of evaluated.
+    real_t r_cov1, r_omc, r_clr, r_prtot, r_psurf, r_den;
+    const real_t den = RC(1.0) + t.zbeta * ptsphy * t.zcorqs;
+    c2_rcp3(t.covptot1, t.omc, t.covpclr, r_cov1, r_omc, r_clr);
+    c2_rcp3(t.zprtot, x.paph_surf, den, r_prtot, r_psurf, r_den);
+    const real_t r_omc2 = r_omc * r_omc, iz = zcons2 * t.zdp;  // iz = 1 / ZDTGDP5
+    real_t zpreclr = (t.zprtot * zcovpclr + t.covpclr * zprtot) * r_cov1 - t.zprtot * t.covpclr * zcovptot * (r_cov1 * r_cov1);
+    real_t zqe = dx.qs - ((x.qs - t.zqlim) * zcovpclr + t.covpclr * dx.qs - t.covpclr * zqlim) * r_omc2 -
+                 RC(2.0) * (x.qs - t.zqlim) * t.covpclr * pclc * (r_omc2 * r_omc);
+    real_t zbeta = RC(0.5777) * t.zbeta * (zpreclr * (t.covptot1 * r_prtot * r_clr) + RC(0.5) * dx.pap * t.zqp -
+                                           RC(0.5) * dx.paph_surf * r_psurf - zcovpclr * r_clr);
+    real_t zb = ptsphy * ((x.qs - t.zqe) * zbeta + t.zbeta * dx.qs - t.zbeta * zqe) * r_den -
+                (ptsphy * ptsphy) * t.zbeta * (x.qs - t.zqe) * (t.zbeta * zcorqs + t.zcorqs * zbeta) * (r_den * r_den);
+    real_t zdtgdp = -ptsphy * rg * (dx.paph_k1 - dx.paph_k) * rdp2;
+    real_t zdpr = (t.covpclr * zb + t.zb * zcovpclr) * iz - t.covpclr * t.zb * zdtgdp * (iz * iz);
+    if (t.dpr_clip) zdpr = zpreclr;
+    zpreclr = zpreclr - zdpr;
+    if (t.reset) zcovptot = pclc;
+    pcovptot = zcovptot;
+    const real_t q2 = t.zdpr * zprtot * (r_prtot * r_prtot);
+    zevapr = (t.zdpr * zrfln + t.rfln2 * zdpr) * r_prtot - t.rfln2 * q2;
+    zevaps = (t.zdpr * zsfln + t.sfln2 * zdpr) * r_prtot - t.sfln2 * q2;
+#else
     real_t zpreclr = (t.zprtot * zcovpclr + t.covpclr * zprtot) / t.covptot1 -
                      t.zprtot * t.covpclr * zcovptot / (t.covptot1 * t.covptot1);
     real_t omc2 = t.omc * t.omc;
@@ -1076,6 +1107,7 @@ C2_HD void level_tl(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
     pcovptot = zcovptot;
     zevapr = (t.zdpr * zrfln + t.rfln2 * zdpr) / t.zprtot - t.zdpr * t.rfln2 * zprtot / (t.zprtot * t.zprtot);
     zevaps = (t.zdpr * zsfln + t.sfln2 * zdpr) / t.zprtot - t.zdpr * t.sfln2 * zprtot / (t.zprtot * t.zprtot);
+#endif
     zrfln = zrfln - zevapr;
     zsfln = zsfln - zevaps;
   }
@@ -1299,6 +1331,62 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
   real_t a_prtot = RC(0.0);
   if (t.llo2) {
     real_t zdpr = RC(0.0), zpreclr = RC(0.0), zb = RC(0.0), zbeta = RC(0.0), zqe = RC(0.0), a_dtgdp = RC(0.0);
+#if C2_EVAP_FAST_TLAD
+    // the transpose of level_tl's fast block, term by term: six reciprocals from two refined v_rcp_f64, 1 / ZDTGDP5 = dp / (dt g),
+    // and the adjoint of ZBETA through dB / B (w = 0.5777 ZBETA5 zbeta*), the power and the root cancelled
+    real_t r_cov1, r_omc, r_clr, r_prtot, r_psurf, r_den;
+    const real_t den = RC(1.0) + t.zbeta * ptsphy * t.zcorqs;
+    c2_rcp3(t.covptot1, t.omc, t.covpclr, r_cov1, r_omc, r_clr);
+    c2_rcp3(t.zprtot, x.paph_surf, den, r_prtot, r_psurf, r_den);
+    const real_t r_omc2 = r_omc * r_omc, iz = zcons2 * t.zdp, r_prtot2 = r_prtot * r_prtot;
+    // ice proportion
+    a_evaps -= a_sfln;
+    a_sfln += t.zdpr * a_evaps * r_prtot;
+    zdpr += t.sfln2 * a_evaps * r_prtot;
+    a_prtot -= t.zdpr * t.sfln2 * a_evaps * r_prtot2;
+    // warm proportion
+    a_evapr -= a_rfln;
+    a_rfln += t.zdpr * a_evapr * r_prtot;
+    zdpr += t.rfln2 * a_evapr * r_prtot;
+    a_prtot -= t.zdpr * t.rfln2 * a_evapr * r_prtot2;
+    // clear-sky flux
+    a_covptot += ya.covptot;
+    if (t.reset) { a_clc += a_covptot; a_covptot = RC(0.0); }
+    zdpr -= zpreclr;
+    if (t.dpr_clip) { zpreclr += zdpr; zdpr = RC(0.0); }
+    zb += t.covpclr * zdpr * iz;
+    a_covpclr += t.zb * zdpr * iz;
+    a_dtgdp -= t.covpclr * t.zb * zdpr * (iz * iz);
+    {
+      real_t g = ptsphy * rg * a_dtgdp * (t.rdp * t.rdp);
+      a_paph_k1 -= g;
+      a_paph_k += g;
+    }
+    // implicit solution
+    const real_t pz = ptsphy * zb * r_den;
+    zbeta += (x.qs - t.zqe) * pz;
+    a_qs += t.zbeta * pz;
+    zqe -= t.zbeta * pz;
+    const real_t p2 = ptsphy * t.zbeta * (x.qs - t.zqe) * pz * r_den;
+    a_corqs -= p2 * t.zbeta;
+    zbeta -= p2 * t.zcorqs;
+    // zbeta
+    const real_t w = RC(0.5777) * t.zbeta * zbeta;
+    zpreclr += w * (t.covptot1 * r_prtot * r_clr);
+    a_pap += RC(0.5) * w * t.zqp;
+    a_paph_surf -= RC(0.5) * w * r_psurf;
+    a_covpclr -= w * r_clr;
+    // zqe
+    a_qs += zqe;
+    a_covpclr -= (x.qs - t.zqlim) * zqe * r_omc2;
+    a_qs -= t.covpclr * zqe * r_omc2;
+    a_qlim += t.covpclr * zqe * r_omc2;
+    a_clc -= RC(2.0) * (x.qs - t.zqlim) * t.covpclr * zqe * (r_omc2 * r_omc);
+    // zpreclr
+    a_covpclr += t.zprtot * zpreclr * r_cov1;
+    a_prtot += t.covpclr * zpreclr * r_cov1;
+    a_covptot -= t.zprtot * t.covpclr * zpreclr * (r_cov1 * r_cov1);
+#else
     // ice proportion
     a_evaps -= a_sfln;
     a_sfln += t.zdpr * a_evaps / t.zprtot;
@@ -1346,6 +1434,7 @@ C2_HD void level_ad(ConstsP c, const LevelCst& k, const LevelIn& x, const LevelT
     a_covpclr += t.zprtot * zpreclr / t.covptot1;
     a_prtot += t.covpclr * zpreclr / t.covptot1;
     a_covptot -= t.zprtot * t.covpclr * zpreclr / (t.covptot1 * t.covptot1);
+#endif
     a_evapr = RC(0.0);
     a_evaps = RC(0.0);
   }
