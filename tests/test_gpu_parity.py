@@ -1064,6 +1064,50 @@ def test_test_drivers_against_the_reference_drivers_run_here(nproma, ngptot):
     assert err < 100 and zad < 100, (err, zad)  # both a few epsilon (the reference's threshold is 1e4)
 
 
+def test_test_drivers_with_the_evaporation_branch_against_the_reference_drivers():
+    """LEVAPLS2 = .TRUE. (off in every shipped main) through the reference's own CLOUDSC_DRIVER_TL and CLOUDSC_DRIVER_AD run here
+    (oracle/_ref) and through ours: the Taylor ratios agree where they are not finite-difference noise -- the tangent block of the
+    branch is evaluated in the log-derivative form since round 5 (level_tl: 0.5777 ZBETA5 dB / B, no pow) against the reference's
+    cloudsc2tl.F90:871-882 --, the ratios converge to 1, and the adjoint test passes in both with a maximum error of a few epsilon."""
+    import re
+    import sys
+
+    if not refcall.have_ref():
+        pytest.skip("needs oracle/_ref (the reference drivers) on the box")
+    tab = c2.random_table(137, 100, seed=5)   # (non-zero PSUPSAT and cloud tendencies; the branch is exercised in most columns)
+    ref = refcall.RefLib()
+    nproma, ngptot = 50, 130
+    prm = c2.default_params(c2.ceta_from_table(tab), lregcl=False, levapls2=True)
+    set_lib_params(ref, prm)
+    st = c2.state_from_table(tab, nproma, ngptot)
+    sys.stdout.flush()
+    txt = refcall.RefLib._capture(1, lambda: ref.driver(1, 1, nproma, st.nlev, ngptot, st.ptsphy, st.driver_arrays()))
+    want = np.array([float(m.group(1)) for m in re.finditer(r"^\s*\d+\s+([0-9.Ee+-]+)\s*$", txt, flags=re.M)][:10])
+    zn, ok, itest, _ = c2.run_state(prm, c2.state_from_table(tab, nproma, ngptot), "tl")
+    print("Taylor ratios with LEVAPLS2: reference", want, "| GPU", zn, ok, itest)
+    assert want.shape == (10,), txt
+    verdict = re.search(r"TEST (PASSED|FAILLED).*", txt).group(0).strip()
+    # with the branch on the increments of lambda >= 1e-4 cross its clip / reset discontinuities (ratios 49 ... 10 907 in the reference
+    # itself: `TEST FAILLED, err 13`); from lambda = 1e-5 on the ratio is 1 + 1.6e-6, 1 + 1.6e-7, ...: the tangent IS the derivative
+    assert verdict == "TEST FAILLED, err  13" and not ok and itest == 13, (verdict, ok, itest)
+    assert np.allclose(zn[:4], want[:4], rtol=1e-5, atol=0), (zn, want)  # (measured: equal to 1e-6, discontinuities and all)
+    assert np.allclose(zn[4:6], want[4:6], rtol=1e-6, atol=0), (zn, want)
+    assert abs(zn[5] - 1.0) < abs(zn[4] - 1.0) < 1e-5
+    got = c2.state_from_table(tab, nproma, ngptot)
+    c2.run_state(prm, got, "nl")
+    assert np.any(got.PCOVPTOT != 0.0)  # the branch really ran
+
+    prm = c2.default_params(c2.ceta_from_table(tab), lregcl=True, levapls2=True)
+    set_lib_params(ref, prm)
+    st = c2.state_from_table(tab, nproma, ngptot)
+    txt = refcall.RefLib._capture(1, lambda: ref.driver(2, 1, nproma, st.nlev, ngptot, st.ptsphy, st.driver_arrays()))
+    err = float(re.search(r"maximum error is\s+([0-9.Ee+-]+)", txt).group(1))
+    zad, ok_ad, _ = c2.run_state(prm, c2.state_from_table(tab, nproma, ngptot), "ad")
+    print("adjoint test with LEVAPLS2: reference", err, "eps | GPU", zad, "eps")
+    assert "TEST OK" in txt and ok_ad
+    assert err < 200 and zad < 200, (err, zad)  # both a few epsilon (the reference's threshold is 1e4)
+
+
 def test_pacing_of_partial_rounds_changes_no_bits():
     """TL / AD launches of a few partial rounds of workgroups are paced (cloudsc2_column.hpp: struct Pace -- workgroups whose slot has
     one workgroup less to run nap at every level; 140 000 columns = 1094 workgroups on 512 slots: 2 rounds + 70): a matter of WHEN
