@@ -99,6 +99,13 @@ def test_resident_mode_of_the_mains(tmp_path):
     a, b = _summary(one), _summary(out)
     for k in a:
         assert a[k][0] == b[k][0] and a[k][1] == b[k][1] and abs(a[k][2] - b[k][2]) <= 1e-10 * abs(a[k][2]), k
+    # the default mode (the sweep resident, then the reference flow, both rates printed) with two ranks: one summary, rank 0's two lines
+    out, err = _run([LAUNCH, 2, exe, 1, 3000, 64], env={"CLOUDSC2_COMM": "shm"}, cwd=tmp_path)
+    b = _summary(out)
+    for k in a:
+        assert a[k][0] == b[k][0] and a[k][1] == b[k][1] and abs(a[k][2] - b[k][2]) <= 1e-10 * abs(a[k][2]), k
+    assert err.count("NUMPROC=2,") == 2 and err.count("state resident on the GPU (cloudsc2_state_*") == 1, err
+    assert err.count("CLOUDSC_DRIVER on host arrays (the reference flow, PCIe-bound)") == 1, err
 
 
 def test_resident_validation_against_a_reference_file(tmp_path):

@@ -1089,7 +1089,7 @@ def test_test_drivers_with_the_evaporation_branch_against_the_reference_drivers(
     verdict = re.search(r"TEST (PASSED|FAILLED).*", txt).group(0).strip()
     # with the branch on the increments of lambda >= 1e-4 cross its clip / reset discontinuities (ratios 49 ... 10 907 in the reference
     # itself: `TEST FAILLED, err 13`); from lambda = 1e-5 on the ratio is 1 + 1.6e-6, 1 + 1.6e-7, ...: the tangent IS the derivative
-    assert verdict == "TEST FAILLED, err  13" and not ok and itest == 13, (verdict, ok, itest)
+    assert verdict.startswith("TEST FAILLED") and verdict.split()[-1] == "13" and not ok and itest == 13, (verdict, ok, itest)
     assert np.allclose(zn[:4], want[:4], rtol=1e-5, atol=0), (zn, want)  # (measured: equal to 1e-6, discontinuities and all)
     assert np.allclose(zn[4:6], want[4:6], rtol=1e-6, atol=0), (zn, want)
     assert abs(zn[5] - 1.0) < abs(zn[4] - 1.0) < 1e-5
