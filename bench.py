@@ -19,7 +19,7 @@ is the same measurement in a fresh process with the placement switched off.
 
 The line also carries `cpu_baseline` (the reference on rank 0's host cores) and, at N=1, from child processes run
 after the measurement: `companion_kernels` (the same bench for TL and AD -- BASELINE.json's metric names all three; AD with its
-design floor, ad_design_floor), `nproma_sweep` (NL at NPROMA 32 / 64 / 128 / 256, BASELINE configs[1]), `target_config` (NL at
+design floor, ad_design_floor), `nproma_sweep` (NL at NPROMA 32 / 64 / 128 / 256, BASELINE configs[1]), `roofline.traffic` measured in this run (two `rocprofv3 --pmc` child passes), `target_config` (NL at
 1 048 576 columns, north_star's target), `host_array_driver` (the PCIe-inclusive rate of the reference-signature path, never `value`)
 `self_tests` (the Taylor test and the adjoint test on a resident state of the same size: verdicts and kernel time) and
 `baseline_configs_2_3` (BASELINE configs[2] and [3] at their own sizes: the Taylor test at 100 columns, the adjoint test at 16 384).  At N > 1
@@ -78,6 +78,43 @@ def select_pmc_traffic(pdir, kernel, ngptot, real_bytes, algorithmic_bytes):
         info["traffic_rejected"] = f"{traffic:.4g} B is below the algorithmic {algorithmic_bytes:.4g} B"
         return None, info
     return traffic, info
+
+
+def measure_pmc_traffic(ngptot, precision, real_bytes, timeout_s=150.0):
+    """HBM traffic per launch of NL / TL / AD measured NOW, as MI355X_MICROARCH.md's HBM section prescribes: two child runs of
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, no trace flags, the program itself after `--`) over
+    tools/pmc_workload.py at this launch size, attributed by dispatch order and calibrated on the SATUR dispatch (tools/pmc_parse.py).
+    Returns the parsed dict; raises when the profiler is missing, a pass fails or runs past `timeout_s` (the caller then falls back
+    to the committed pass).  Each child is its own process group, killed as a whole at the deadline."""
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+
+    from tools import pmc_parse
+
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        raise RuntimeError("rocprofv3 not found")
+    tmp = tempfile.mkdtemp(prefix="cloudsc2_pmc_", dir="/tmp")
+    env = {**os.environ, "CLOUDSC2_PLACE": "0", "PMC_NGPTOT": str(ngptot), "CLOUDSC2_PRECISION": precision, "TMPDIR": "/tmp"}
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        for counter, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+            cmd = [rp, "--pmc", counter, "--output-format", "csv", "-d", os.path.join(tmp, sub), "--", "python3", os.path.join(ROOT, "tools", "pmc_workload.py")]
+            p = subprocess.Popen(cmd, env=env, cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, start_new_session=True)
+            try:
+                outp, _ = p.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)
+                p.wait()
+                raise RuntimeError(f"rocprofv3 --pmc {counter}: no end after {timeout_s:g} s") from None
+            if p.returncode != 0 or "pmc workload done" not in outp:
+                raise RuntimeError(f"rocprofv3 --pmc {counter} failed (rc {p.returncode}): {outp[-300:]}")
+        return pmc_parse.traffic(os.path.join(tmp, "fetch"), os.path.join(tmp, "write"), ngptot, real_bytes)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def roofline_fractions(kernel_ms, ngptot, bytes_per_column, kernel_only_bytes_per_column=None, traffic_bytes=None, peak_gbs=HBM_PEAK_GBS):
@@ -409,6 +446,9 @@ def main():
     ap.add_argument("--no-companions", action="store_true",
                     help="skip everything appended to the headline line from child processes: TL and AD timings, the 1 M-column "
                          "NL target configuration, the unplaced first allocation")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not measure the HBM traffic in this run (two rocprofv3 --pmc child passes, ~25 s): `roofline.traffic` then comes "
+                         "from the newest committed pass under profiles/")
     ap.add_argument("--precision", choices=["double", "single"], default=os.environ.get("CLOUDSC2_PRECISION", "double"),
                     help="single = the fp32 library (the reference's -DSINGLE build); the headline metric is double")
     ap.add_argument("--ad-assign", action="store_true",
@@ -548,9 +588,10 @@ def main():
 
     k_avg = float(kms.mean())
     k_per_rank = c2dist.allgather_scalar(k_avg, dev) if world > 1 else [k_avg]
-    # HBM traffic: NOT measured in this run.  It is the figure of the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
-    # separate runs, calibrated as the MI355X guide prescribes; tools/pmc_workload.py + tools/pmc_parse.py), scaled per column
-    # to this launch; `traffic_source` names the file, null if there is none for this precision.
+    # HBM traffic: first the figure of the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, calibrated as the
+    # MI355X guide prescribes; tools/pmc_workload.py + tools/pmc_parse.py), scaled per column to this launch (`traffic_source` names
+    # the file); the default one-GPU run then MEASURES it itself in two child passes (measure_pmc_traffic, companions below) and
+    # replaces the figure -- `traffic_source` says which of the two the line carries.
     tkey = args.kernel
     if args.kernel == "ad":
         tkey = ("ad" if args.ad_sweep == "both" else "ad_reverse") + ("_assign" if args.ad_assign else "")
@@ -626,6 +667,32 @@ def main():
             except Exception as e:  # noqa: BLE001  (never let the companions break the headline line)
                 comp[kind] = {"error": repr(e)}
         out["companion_kernels"] = comp
+        # (1a) HBM traffic measured in THIS run (the line used to carry a committed pass only): replaces the figures
+        # chosen from profiles/ above for NL and for the two companions; on any failure the committed figures stay, and say so
+        if not args.no_pmc and not args.levapls2:
+            try:
+                t0 = time.perf_counter()
+                pm = measure_pmc_traffic(args.ngptot, args.precision, c2.binding.REAL_BYTES)
+                how = (f"measured in this run: two child passes of rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over tools/pmc_workload.py at {args.ngptot} "
+                       f"columns (first plain hipMalloc of their processes), calibrated on the SATUR dispatch (read factor "
+                       f"{pm['calibration']['read_factor']:.4f}); {time.perf_counter() - t0:.0f} s")
+
+                def apply(dst, key, kernel_ms):
+                    k = pm["kernels"][key]
+                    dst["traffic_committed_pass"] = {"traffic": dst.get("traffic"), "traffic_source": dst.get("traffic_source")}
+                    dst["traffic"] = k["traffic_bytes"]
+                    dst["traffic_over_algorithmic"] = k["traffic_over_algorithmic"]
+                    dst["frac_actual_bytes"] = k["traffic_bytes"] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                    dst["traffic_source"] = how
+                    dst["traffic_read_bytes"], dst["traffic_write_bytes"] = k["read_bytes"], k["write_bytes"]
+
+                if abs(pm["kernels"]["nl"]["algorithmic_bytes"] - bpc * args.ngptot) < 1e-6 * bpc * args.ngptot:
+                    apply(out["roofline"], "nl", k_avg)
+                for kind in ("tl", "ad"):
+                    if "kernel_ms_avg" in comp.get(kind, {}):
+                        apply(comp[kind], kind, comp[kind]["kernel_ms_avg"])
+            except Exception as e:  # noqa: BLE001
+                out["roofline"]["traffic_measurement_failed"] = repr(e)[:400]
         # (1b) BASELINE.json configs[1] names an NPROMA sweep 32-256: the same NL bench at the other three blockings, each in a fresh
         # process with its own placed state (the headline's own blocking is this run's figure)
         sweep = {str(args.nproma): {"kernel_ms_avg": k_avg, "frac": fr["frac"], "value": value, "steps": args.steps, "source": "this run (the headline)"}}

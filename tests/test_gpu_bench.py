@@ -89,6 +89,14 @@ def test_the_default_line_carries_the_nproma_sweep_and_the_adjoints_floor():
     assert ad["bytes_per_column"] == 85608 and ad["bytes_per_column_design_floor"] == 103152
     assert abs(ad["frac_design_floor"] - 103152 * 160000 / (ad["kernel_ms_avg"] * 1e-3) / 8e12) < 1e-9 and ad["frac_design_floor"] > ad["frac"]
     assert "bytes_per_column_design_floor" not in d["companion_kernels"]["tl"]
+    # the HBM traffic of the line is measured in this very run (two rocprofv3 --pmc child passes), not quoted from an earlier one
+    rf = d["roofline"]
+    assert rf["traffic_source"].startswith("measured in this run"), rf.get("traffic_measurement_failed", rf["traffic_source"])
+    assert 1.0 <= rf["traffic_over_algorithmic"] < 1.06 and abs(rf["traffic"] - rf["traffic_read_bytes"] - rf["traffic_write_bytes"]) < 1.0
+    assert abs(rf["frac_actual_bytes"] - rf["traffic"] / (rf["kernel_ms_avg"] * 1e-3) / 8e12) < 1e-9
+    assert "profiles/" in rf["traffic_committed_pass"]["traffic_source"]
+    assert 1.0 <= d["companion_kernels"]["tl"]["traffic_over_algorithmic"] < 1.05 and 1.15 < ad["traffic_over_algorithmic"] < 1.25
+    assert ad["traffic_source"].startswith("measured in this run")
     # BASELINE configs[2] and [3] at their own sizes, in the same line
     bc = d["baseline_configs_2_3"]
     assert "error" not in bc, bc

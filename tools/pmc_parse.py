@@ -64,9 +64,8 @@ def per_launch(dirname, counter):
     return out
 
 
-def main():
-    fetch_dir, write_dir, ngptot = sys.argv[1], sys.argv[2], int(sys.argv[3])
-    rb = int(sys.argv[4]) if len(sys.argv) > 4 else 8  # bytes per real: 4 for the fp32 library (CLOUDSC2_PRECISION=single)
+def traffic(fetch_dir, write_dir, ngptot, rb=8):
+    """The parsed result as a dict (bench.py measures the traffic in its own run through this)."""
     nlev = 137
     from dwarf_p_cloudsc2_tl_ad_amd.state import bytes_per_column as bpc
 
@@ -88,7 +87,13 @@ def main():
         out["kernels"][k] = {"read_bytes": rd, "write_bytes": wr, "traffic_bytes": rd + wr, "algorithmic_bytes": algo[k] * ngptot,
                              "traffic_over_algorithmic": (rd + wr) / (algo[k] * ngptot), "raw_fetch_kib": fetch[k][0],
                              "raw_write_kib": write[k][0]}
-    print(json.dumps(out, indent=1))
+    return out
+
+
+def main():
+    fetch_dir, write_dir, ngptot = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    rb = int(sys.argv[4]) if len(sys.argv) > 4 else 8  # bytes per real: 4 for the fp32 library (CLOUDSC2_PRECISION=single)
+    print(json.dumps(traffic(fetch_dir, write_dir, ngptot, rb), indent=1))
 
 
 if __name__ == "__main__":
