@@ -1223,7 +1223,7 @@ def test_launches_under_stream_capture_are_plain_kernel_nodes():
     from tests.util import ROOT
 
     e = {k: v for k, v in os.environ.items() if not k.startswith(("CLOUDSC2_PACE", "CLOUDSC2_NL_LIGHT"))}
-    for mode in ("cold", "warm"):
+    for mode in ("cold",):  # (the captured launches are the first of their process -- the level table included; `warm` stays in the tool)
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "capture_probe.py"), mode], capture_output=True, text=True, timeout=600,
                            env={**e, "CLOUDSC2_PACE_VERBOSE": "1"})
         assert r.returncode == 0 and f"CAPTURE OK {mode}" in r.stdout, (mode, r.stdout[-500:], r.stderr[-3000:])
