@@ -97,6 +97,10 @@ def test_the_default_line_carries_the_nproma_sweep_and_the_adjoints_floor():
     assert "profiles/" in rf["traffic_committed_pass"]["traffic_source"]
     assert 1.0 <= d["companion_kernels"]["tl"]["traffic_over_algorithmic"] < 1.05 and 1.15 < ad["traffic_over_algorithmic"] < 1.25
     assert ad["traffic_source"].startswith("measured in this run")
+    # guards against a gross performance regression (boxes of the pool measure up to 12 % apart: measured 0.733-0.747 NL, 0.754-0.773 at
+    # 1 M columns, 0.72-0.73 TL, 0.73-0.76 of the adjoint's floor; north_star's bar is 0.70 for NL at >= 1 M columns)
+    assert rf["frac"] >= 0.65 and d["target_config"]["frac"] >= 0.66, (rf["frac"], d["target_config"]["frac"])
+    assert d["companion_kernels"]["tl"]["frac"] >= 0.63 and ad["frac_design_floor"] >= 0.63, (d["companion_kernels"]["tl"]["frac"], ad["frac_design_floor"])
     # BASELINE configs[2] and [3] at their own sizes, in the same line
     bc = d["baseline_configs_2_3"]
     assert "error" not in bc, bc
