@@ -183,3 +183,29 @@ def test_without_a_gpu_the_bench_fails_loudly():
     assert r.returncode != 0 and "no CPU path" in (r.stderr + r.stdout)
     r = _run(["--host-driver-rate", "--ngptot", 100])  # and the host-array driver's rate
     assert r.returncode != 0 and "no CPU path" in (r.stderr + r.stdout)
+
+
+def test_the_pmc_parser_reproduces_the_committed_traffic_from_the_raw_counters(tmp_path):
+    """bench.py measures its HBM traffic through tools/pmc_parse.traffic (two rocprofv3 --pmc passes, dispatches attributed by order
+    against tools/pmc_plan.py, read / write factors calibrated on the SATUR dispatch).  The parser on the round's committed RAW counter
+    files gives the committed figures exactly: NL 1.021, TL 1.007, AD 1.198 x the algorithmic bytes, read factor 1.9996 (gfx950
+    halves FETCH_SIZE for wide coalesced reads)."""
+    import shutil
+
+    from tools import pmc_parse
+
+    raw = os.path.join(ROOT, "profiles", "r05_f_pmc_raw")
+    for n in (160000, 1048576):
+        for w in ("fetch", "write"):
+            d = tmp_path / f"{w}_{n}" / "x"
+            d.mkdir(parents=True)
+            shutil.copy(os.path.join(raw, f"{w}_{n}_counter_collection.csv"), d / "1_counter_collection.csv")
+        got = pmc_parse.traffic(str(tmp_path / f"fetch_{n}"), str(tmp_path / f"write_{n}"), n, 8)
+        want = json.load(open(os.path.join(ROOT, "profiles", f"r05_f_{n}_pmc_traffic.json")))
+        assert got == want, n
+        k = got["kernels"]
+        assert abs(got["calibration"]["read_factor"] - 2.0) < 2e-3 and abs(got["calibration"]["write_factor"] - 1.0) < 2e-3
+        assert 1.01 < k["nl"]["traffic_over_algorithmic"] < 1.03 and 1.0 < k["tl"]["traffic_over_algorithmic"] < 1.02
+        assert 1.18 < k["ad"]["traffic_over_algorithmic"] < 1.21
+        # the adjoint's excess IS the second read of the trajectory inputs: traffic ~ the design floor of 103 152 B per column
+        assert abs(k["ad"]["traffic_bytes"] / n / 103152 - 1.0) < 0.01, k["ad"]["traffic_bytes"] / n
