@@ -1231,3 +1231,66 @@ def test_launches_under_stream_capture_are_plain_kernel_nodes():
         assert "dispatch probe on device" in r.stderr and "pace probe on device" in r.stderr, r.stderr[-3000:]
         if "TL / AD pacing is on" in r.stderr:
             assert r.stderr.index("pace probe on device") < r.stderr.index("launch of 1094 workgroups on 512 slots paced"), r.stderr[-3000:]
+
+
+def test_launchers_called_from_four_host_threads_at_once():
+    """The reference's kernels are called concurrently from NUMOMP threads on disjoint blocks (cloudsc_driver_mod.F90:73-119); the
+    counterpart here: four host threads, each with its own state and its own stream, launching NL, SATUR, TL and AD at once in a FRESH
+    process -- so that the first-use paths race too: the level tables of two vertical grids, the occupancy caches, the pacing
+    decisions, the per-call arithmetic mode (two threads fast, two precise).  Every thread's results equal, bit for bit, what the same
+    calls give one after the other; and the host-array driver (one workspace, serialised by the library) survives two threads."""
+    import subprocess
+    import sys
+
+    from tests.util import ROOT
+
+    code = r'''
+import sys, threading; sys.path.insert(0, %r)
+import numpy as np, torch, dwarf_p_cloudsc2_tl_ad_amd as c2
+specs = [(137, 128, 20000, 1), (91, 64, 9000, 2), (137, 32, 5000, 2), (91, 100, 12345, 1)]   # (nlev, nproma, ngptot, math mode)
+def make(nlev, nproma, ngptot, mode):
+    tab = c2.random_table(nlev, 60, seed=nlev + nproma)
+    prm = c2.default_params(c2.ceta_from_table(tab), lregcl=True); prm.math_mode = mode
+    ds = c2.DeviceState.from_table(tab, nproma, ngptot)
+    dx = c2.FlatFields("in", ds.nb, ds.nlev, ds.nproma, ds.device); dy = c2.FlatFields("out", ds.nb, ds.nlev, ds.nproma, ds.device)
+    xa = c2.FlatFields("in", ds.nb, ds.nlev, ds.nproma, ds.device)
+    return prm, ds, dx, dy, xa
+def work(item, stream, reps):
+    prm, ds, dx, dy, xa = item
+    for _ in range(reps):
+        ds.nl(prm, stream); ds.satur(prm, stream); ds.increments(zero_supsat=True, into=dx)
+        ds.tl(prm, dx, dy, stream); xa.zero_(); ds.ad(prm, xa, dy, ds.new_scratch(), stream)
+def digest(item):
+    prm, ds, dx, dy, xa = item
+    torch.cuda.synchronize()
+    return [t.clone() for t in (ds.B_LOC, ds.PA, ds.PCOVPTOT, ds.PFPLSL, ds.PFPLSN, ds.PFHPSL, ds.PFHPSN)] + [xa.t[k].clone() for k in sorted(xa.t)]
+items = [make(*s) for s in specs]          # (allocation = the synchronous moment: the device is prepared; nothing has been launched yet)
+streams = [torch.cuda.Stream() for _ in specs]
+errs = []
+def guarded(i):
+    try:
+        with torch.cuda.stream(streams[i]):
+            work(items[i], streams[i], 5)
+    except Exception as e:
+        errs.append(repr(e))
+th = [threading.Thread(target=guarded, args=(i,)) for i in range(4)]
+[t.start() for t in th]; [t.join() for t in th]
+assert not errs, errs
+par = [digest(it) for it in items]
+for i, it in enumerate(items):             # the same calls one after the other, on the default stream
+    work(it, None, 1)
+seq = [digest(it) for it in items]
+for a, b in zip(par, seq):
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+# the host-array driver from two threads: one workspace, serialised inside the library
+tab = c2.synthetic_table(); prm = c2.default_params(c2.ceta_from_table(tab))
+sts = [c2.state_from_table(tab, 64, 3000), c2.state_from_table(tab, 128, 5000)]
+th = [threading.Thread(target=lambda s=s: c2.run_state(prm, s, "nl")) for s in sts]
+[t.start() for t in th]; [t.join() for t in th]
+for s in sts:
+    r = c2.state_from_table(tab, s.nproma, s.ngptot); c2.run_state(prm, r, "nl")
+    assert all(np.array_equal(a, b) for a, b in zip(s.outputs().values(), r.outputs().values()))
+print("THREADS OK")
+''' % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "THREADS OK" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
