@@ -61,7 +61,7 @@ def assert_outputs_close(ref_st, got_st, tol):
 
 
 @pytest.mark.parametrize("nproma,ngptot", [(32, 100), (64, 100), (100, 100), (128, 300), (1, 7), (256, 1000), (1000, 2500),
-                                           (512, 100)])
+                                           (512, 100), (64, 1), (128, 129)])
 def test_nl_driver_matches_checker(nproma, ngptot):
     tab = c2.synthetic_table()
     prm = c2.default_params(c2.ceta_from_table(tab))
